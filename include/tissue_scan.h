@@ -1,0 +1,153 @@
+/* tissue_scan.h -- C ABI of the MI355X-native per-label voxel-scan library (libtissue_scan.so).
+ *
+ * The reference (VirtualPlants/tissue_analysis, pure Python 2) has NO plugin / operator / FFI
+ * interface for this path: its boundary is the Python class API of
+ * src/vplants/tissue_analysis/spatial_image_analysis.py (SIA).  This header is therefore the
+ * binding a maintainer of the reference would add underneath that class; every entry point
+ * cites the reference code whose arithmetic it replaces.  INTEGRATION.md shows the ctypes stub.
+ *
+ * Conventions
+ *  - every function returns TA_OK (0) or a negative TA_E* code; ta_last_error() gives the text
+ *    (thread-local, valid until the next call on that thread);
+ *  - no C++ exceptions, Python callbacks, or torch types cross this boundary -- plain pointers
+ *    and sizes only; all host output buffers are caller-allocated, the library never returns
+ *    owned host memory;
+ *  - a ta_ctx is bound to ONE GPU (one process per GPU; multi-GPU = one context per rank plus
+ *    RCCL collectives issued by the host on the device buffers exposed below); a context is
+ *    not thread-safe, distinct contexts may be used from different threads;
+ *  - axes: "memory axis 0" is the slowest-varying axis of the volume, axis 2 the fastest.
+ *    ta_volume_set() accepts any dense permuted layout (C- or F-ordered numpy arrays) and the
+ *    host getters report per-axis outputs in ARRAY axis order; the device-resident entry points
+ *    take dense C-ordered buffers (array order == memory order);
+ *  - all per-label outputs are exact integers.  Float work (barycentre = sum1/count, covariance,
+ *    eigen-decomposition, real-unit scaling) is host-side float64 on these integers.
+ */
+#ifndef TISSUE_SCAN_H
+#define TISSUE_SCAN_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TA_ABI_VERSION 1
+
+#if defined(TA_BUILD)
+#define TA_API __attribute__((visibility("default")))
+#else
+#define TA_API
+#endif
+
+/* status codes */
+#define TA_OK          0
+#define TA_EINVAL     -1  /* bad argument / call order                                   */
+#define TA_EHIP       -2  /* HIP runtime error (text in ta_last_error)                   */
+#define TA_ENOMEM     -3  /* host or device allocation failed                            */
+#define TA_ERANGE     -4  /* the volume holds a label above max_label                    */
+#define TA_ECAPACITY  -5  /* adjacency table could not grow any further                  */
+#define TA_ENODEVICE  -6  /* no usable GPU                                               */
+
+/* feature mask of ta_extract() */
+#define TA_F_VOLUME     1u  /* count[l]                 ~ nd.sum(ones, image, index)  SIA:1231          */
+#define TA_F_BBOX       2u  /* bbox[l]                  ~ nd.find_objects(image)      SIA:517           */
+#define TA_F_MOMENT1    4u  /* sum1[l][3]               ~ nd.center_of_mass per label SIA:464-467       */
+#define TA_F_MOMENT2    8u  /* sum2[l][6]               ~ cov = P.P^T/N               SIA:137-150,1276  */
+#define TA_F_ADJACENCY 16u  /* faces[(lo,hi)][3]        ~ binary_dilation shells      SIA:45-60,947-956 */
+#define TA_F_ALL       31u
+
+/* ta_ctx_set_option keys */
+#define TA_OPT_IMPL        1  /* 0 = fused LDS sweep (default), 1 = per-voxel atomics (slow, for cross-checks) */
+#define TA_OPT_TILE_PLANES 2  /* planes of memory axis 0 walked by one workgroup (tuning)          */
+#define TA_OPT_PAIR_SLOTS  3  /* log2 of the device adjacency hash capacity (0 = automatic)       */
+
+typedef struct ta_ctx ta_ctx;
+
+TA_API int         ta_version(void);
+TA_API const char* ta_last_error(void);
+TA_API int         ta_device_count(int* count);
+
+/* One context per GPU.  Owns a HIP stream (unless ta_ctx_set_stream replaces it), the resident
+ * volume (when uploaded with ta_volume_set), accumulators, the adjacency hash and timing events. */
+TA_API int ta_ctx_create(int device_id, ta_ctx** out);
+TA_API int ta_ctx_destroy(ta_ctx* ctx);
+TA_API int ta_ctx_set_stream(ta_ctx* ctx, void* hip_stream /* hipStream_t, caller-owned; NULL = own stream */);
+TA_API int ta_ctx_set_option(ta_ctx* ctx, int key, int64_t value);
+TA_API int ta_ctx_synchronize(ta_ctx* ctx);
+
+/* Upload a host volume (SIA:225-227 "self.image").  itemsize 2 (uint16) or 4 (uint32).
+ * strides_bytes == NULL means dense C order; otherwise the strides must describe a dense layout
+ * in SOME axis permutation (C/F-ordered or transposed arrays).  The host buffer stays caller-owned
+ * and may be freed after return. */
+TA_API int ta_volume_set(ta_ctx* ctx, const void* host_ptr, int itemsize,
+                  const int64_t dims[3], const int64_t strides_bytes[3]);
+
+/* Adopt a volume already resident in this GPU's HBM (dense C order, not copied, not owned).
+ * buf_dims[0] counts every plane in the buffer.  For a Z-slab of a larger volume
+ * a0_origin is the global axis-0 coordinate of the first OWNED plane and has_low_halo != 0 says
+ * that plane 0 of the buffer is the neighbour slab's last plane: it only contributes the faces
+ * it shares with plane 1 (a face belongs to the slab owning its higher voxel). */
+TA_API int ta_volume_set_device(ta_ctx* ctx, const void* dev_ptr, int itemsize,
+                         const int64_t buf_dims[3], int64_t a0_origin, int has_low_halo);
+
+/* Largest label in the resident volume (device max-reduction; ~ np.unique(image) SIA:363). */
+TA_API int ta_volume_max_label(ta_ctx* ctx, uint32_t* max_label);
+
+/* The hot path: one fused sweep of the resident volume + adjacency compaction.
+ * Replaces the four per-label Python loops of the reference (SIA:417-480, 632-660, 908-993,
+ * 1246-1292) and its whole-volume scans (SIA:517, 1231).  Asynchronous on the context stream;
+ * the getters synchronise.  Labels above max_label => TA_ERANGE (reported by the getters too). */
+TA_API int ta_extract(ta_ctx* ctx, uint32_t feature_mask, uint32_t max_label);
+
+/* Per-label results, rows 0..max_label, any pointer may be NULL:
+ *   count [L+1]     voxels per label
+ *   bbox  [L+1][6]  min0,min1,min2,max0+1,max1+1,max2+1 ; -1 when the label is absent
+ *   sum1  [L+1][3]  sum of coordinates
+ *   sum2  [L+1][6]  sum of coordinate products, order 00,01,02,11,12,22 */
+TA_API int ta_get_labels(ta_ctx* ctx, uint64_t* count, int32_t* bbox, uint64_t* sum1, uint64_t* sum2);
+
+/* Face-neighbour adjacency (size-then-fill): unique pairs lo<hi sorted by (lo,hi);
+ * faces[i][d] = number of voxel faces normal to ARRAY axis d shared by the pair. */
+TA_API int ta_adjacency_size(ta_ctx* ctx, int64_t* npairs);
+TA_API int ta_adjacency_get(ta_ctx* ctx, uint32_t* lo, uint32_t* hi, uint64_t* faces);
+
+/* Timing of the last ta_extract (HIP events on the context stream): the sweep kernel alone,
+ * the adjacency collection, the whole call; bytes_read = nvox * itemsize (algorithmic bytes). */
+TA_API int ta_timing(ta_ctx* ctx, double* ms_sweep, double* ms_adjacency, double* ms_total,
+              uint64_t* bytes_read);
+
+/* ---- device-side views for the multi-GPU reduce (RCCL runs on these in place) -------------
+ * sums  : uint64 [L+1][10] = count, s0, s1, s2, s00, s01, s02, s11, s12, s22   (reduce: SUM)
+ * boxes : int32  [L+1][6]  = min0, min1, min2, -max0, -max1, -max2 (inclusive max, INT32_MAX
+ *                            when absent)                                      (reduce: MIN)
+ * By default the context owns them; ta_bind_accumulators lets the caller supply device memory
+ * (e.g. torch tensors) sized for max_label so collectives need no copy; ta_get_labels reads
+ * whatever the buffers hold at call time, i.e. the reduced values after an all-reduce. */
+TA_API int ta_bind_accumulators(ta_ctx* ctx, void* sums_dev, void* boxes_dev, uint32_t max_label);
+TA_API int ta_accumulators_device(ta_ctx* ctx, void** sums_dev, void** boxes_dev, uint32_t* max_label);
+
+/* Unsorted unique pairs of the last extraction, on the device:
+ * keys uint64[n] = lo<<32|hi, faces uint64[n][3] (memory-axis order). */
+TA_API int ta_adjacency_device(ta_ctx* ctx, void** keys_dev, void** faces_dev, int64_t* npairs);
+
+/* Merge foreign pair lists (other ranks' ta_adjacency_device output, gathered by the host with
+ * RCCL) into this context's adjacency: sums face counts of equal keys. */
+TA_API int ta_adjacency_merge(ta_ctx* ctx, const void* keys_dev, const void* faces_dev, int64_t npairs);
+
+/* Synthetic workload generator, bit-identical to tissue_analysis_amd/synth.py:
+ * writes planes [a_begin, a_begin+a_count) of the dims[] Voronoi volume to dev_out (dense C).
+ * seeds: host int32 [G0*G1*G2][3]; ell: host int64 tables E0|E1|E2 concatenated, or NULL. */
+TA_API int ta_synth_voronoi(ta_ctx* ctx, void* dev_out, int itemsize, const int64_t dims[3],
+                     int64_t a_begin, int64_t a_count, const int32_t* seeds,
+                     const int32_t grid[3], const int64_t* ell);
+
+/* Raw device memory helpers so a host without torch can still stage buffers. */
+TA_API int ta_device_malloc(ta_ctx* ctx, uint64_t bytes, void** dev_ptr);
+TA_API int ta_device_free(ta_ctx* ctx, void* dev_ptr);
+TA_API int ta_memcpy_d2h(ta_ctx* ctx, void* host_dst, const void* dev_src, uint64_t bytes);
+TA_API int ta_memcpy_h2d(ta_ctx* ctx, void* dev_dst, const void* host_src, uint64_t bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TISSUE_SCAN_H */

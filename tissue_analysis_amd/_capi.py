@@ -1,0 +1,260 @@
+"""ctypes binding of include/tissue_scan.h (libtissue_scan.so).
+
+This is the only door from Python into the HIP kernels.  There is no CPU fallback: if the
+shared library is missing, or no gfx950 GPU is visible, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtissue_scan.so")
+
+TA_OK, TA_EINVAL, TA_EHIP, TA_ENOMEM, TA_ERANGE, TA_ECAPACITY, TA_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
+F_VOLUME, F_BBOX, F_MOMENT1, F_MOMENT2, F_ADJACENCY = 1, 2, 4, 8, 16
+F_ALL = 31
+FEATURES = dict(VOLUME=F_VOLUME, BBOX=F_BBOX, MOMENT1=F_MOMENT1, MOMENT2=F_MOMENT2,
+                ADJACENCY=F_ADJACENCY)
+OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS = 1, 2, 3
+
+# every symbol include/tissue_scan.h declares
+SYMBOLS = (
+    "ta_version", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
+    "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_synchronize", "ta_volume_set",
+    "ta_volume_set_device", "ta_volume_max_label", "ta_extract", "ta_get_labels",
+    "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_bind_accumulators",
+    "ta_accumulators_device", "ta_adjacency_device", "ta_adjacency_merge", "ta_synth_voronoi",
+    "ta_device_malloc", "ta_device_free", "ta_memcpy_d2h", "ta_memcpy_h2d",
+)
+
+
+class TissueScanError(RuntimeError):
+    def __init__(self, code, message):
+        RuntimeError.__init__(self, "libtissue_scan error %d: %s" % (code, message))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load libtissue_scan.so (built in-tree by `python -m tissue_analysis_amd.build`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "%s is missing: the HIP extension has not been built "
+            "(run `python -m tissue_analysis_amd.build`); there is no CPU fallback" % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i64, u32, u64, ci = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64,
+                             ctypes.c_int)
+    P = ctypes.POINTER
+    sig = {
+        "ta_version": (ci, []),
+        "ta_last_error": (ctypes.c_char_p, []),
+        "ta_device_count": (ci, [P(ci)]),
+        "ta_ctx_create": (ci, [ci, P(vp)]),
+        "ta_ctx_destroy": (ci, [vp]),
+        "ta_ctx_set_stream": (ci, [vp, vp]),
+        "ta_ctx_set_option": (ci, [vp, ci, i64]),
+        "ta_ctx_synchronize": (ci, [vp]),
+        "ta_volume_set": (ci, [vp, vp, ci, P(i64), P(i64)]),
+        "ta_volume_set_device": (ci, [vp, vp, ci, P(i64), i64, ci]),
+        "ta_volume_max_label": (ci, [vp, P(u32)]),
+        "ta_extract": (ci, [vp, u32, u32]),
+        "ta_get_labels": (ci, [vp, vp, vp, vp, vp]),
+        "ta_adjacency_size": (ci, [vp, P(i64)]),
+        "ta_adjacency_get": (ci, [vp, vp, vp, vp]),
+        "ta_timing": (ci, [vp, P(ctypes.c_double), P(ctypes.c_double), P(ctypes.c_double), P(u64)]),
+        "ta_bind_accumulators": (ci, [vp, vp, vp, u32]),
+        "ta_accumulators_device": (ci, [vp, P(vp), P(vp), P(u32)]),
+        "ta_adjacency_device": (ci, [vp, P(vp), P(vp), P(i64)]),
+        "ta_adjacency_merge": (ci, [vp, vp, vp, i64]),
+        "ta_synth_voronoi": (ci, [vp, vp, ci, P(i64), i64, i64, vp, P(ctypes.c_int32), vp]),
+        "ta_device_malloc": (ci, [vp, u64, P(vp)]),
+        "ta_device_free": (ci, [vp, vp]),
+        "ta_memcpy_d2h": (ci, [vp, vp, vp, u64]),
+        "ta_memcpy_h2d": (ci, [vp, vp, vp, u64]),
+    }
+    for name in SYMBOLS:
+        fn = getattr(lib, name)      # AttributeError here == the .so does not match the header
+        fn.restype, fn.argtypes = sig[name]
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != TA_OK:
+        raise TissueScanError(rc, load().ta_last_error().decode(errors="replace"))
+
+
+def device_count():
+    n = ctypes.c_int(0)
+    _check(load().ta_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def feature_mask(names):
+    if isinstance(names, int):
+        return names
+    m = 0
+    for n in names:
+        m |= FEATURES[n.upper()]
+    return m
+
+
+def _i64x3(v):
+    return (ctypes.c_int64 * 3)(*[int(x) for x in v])
+
+
+def _dense_permuted(a):
+    """True when the array is dense in some axis permutation (C, F or transposed layouts)."""
+    order = sorted(range(a.ndim), key=lambda d: (a.shape[d] != 1, -a.strides[d]))
+    expect = a.dtype.itemsize
+    for d in reversed(order):
+        if a.shape[d] != 1 and a.strides[d] != expect:
+            return False
+        expect *= a.shape[d]
+    return True
+
+
+class Context(object):
+    """One ta_ctx == one GPU.  Thin, explicit wrapper: every method is one C call."""
+
+    def __init__(self, device=0, stream=None):
+        self._lib = load()
+        self._h = ctypes.c_void_p()
+        _check(self._lib.ta_ctx_create(int(device), ctypes.byref(self._h)))
+        self.device = int(device)
+        self._keep = []      # objects whose device memory the context currently points at
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self._lib.ta_ctx_destroy(self._h)
+            self._h = ctypes.c_void_p()
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # -- plumbing
+    def set_stream(self, stream_handle):
+        _check(self._lib.ta_ctx_set_stream(self._h, ctypes.c_void_p(int(stream_handle) if stream_handle else 0)))
+
+    def set_option(self, key, value):
+        _check(self._lib.ta_ctx_set_option(self._h, int(key), int(value)))
+
+    def synchronize(self):
+        _check(self._lib.ta_ctx_synchronize(self._h))
+
+    # -- volume
+    def set_volume(self, array):
+        """Upload a uint16/uint32 numpy volume in whatever dense layout it has."""
+        a = np.asarray(array)
+        if a.ndim != 3:
+            raise ValueError("a 3D volume is required")
+        if a.dtype not in (np.uint16, np.uint32):
+            raise TypeError("label volumes must be uint16 or uint32, not %s" % a.dtype)
+        if not _dense_permuted(a):
+            a = np.ascontiguousarray(a)
+        _check(self._lib.ta_volume_set(self._h, ctypes.c_void_p(a.ctypes.data), a.dtype.itemsize,
+                                       _i64x3(a.shape), _i64x3(a.strides)))
+
+    def set_volume_device(self, dev_ptr, itemsize, buf_dims, a0_origin=0, has_low_halo=False, keep=None):
+        _check(self._lib.ta_volume_set_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(itemsize),
+                                              _i64x3(buf_dims), int(a0_origin), int(bool(has_low_halo))))
+        self._keep = [keep]
+
+    def max_label(self):
+        v = ctypes.c_uint32(0)
+        _check(self._lib.ta_volume_max_label(self._h, ctypes.byref(v)))
+        return v.value
+
+    # -- hot path
+    def extract(self, features, max_label):
+        _check(self._lib.ta_extract(self._h, feature_mask(features), int(max_label)))
+        self._max_label = int(max_label)
+
+    def labels(self):
+        """(count u64[L+1], bbox i32[L+1,6], sum1 u64[L+1,3], sum2 u64[L+1,6])"""
+        n = self._max_label + 1
+        count = np.zeros(n, dtype=np.uint64)
+        bbox = np.zeros((n, 6), dtype=np.int32)
+        sum1 = np.zeros((n, 3), dtype=np.uint64)
+        sum2 = np.zeros((n, 6), dtype=np.uint64)
+        _check(self._lib.ta_get_labels(self._h, count.ctypes.data, bbox.ctypes.data, sum1.ctypes.data,
+                                       sum2.ctypes.data))
+        return count, bbox, sum1, sum2
+
+    def adjacency(self):
+        """(lo u32[n], hi u32[n], faces u64[n,3]) sorted by (lo, hi)."""
+        n = ctypes.c_int64(0)
+        _check(self._lib.ta_adjacency_size(self._h, ctypes.byref(n)))
+        lo = np.zeros(n.value, dtype=np.uint32)
+        hi = np.zeros(n.value, dtype=np.uint32)
+        faces = np.zeros((n.value, 3), dtype=np.uint64)
+        _check(self._lib.ta_adjacency_get(self._h, lo.ctypes.data, hi.ctypes.data, faces.ctypes.data))
+        return lo, hi, faces
+
+    def timing(self):
+        a, b, t = ctypes.c_double(0), ctypes.c_double(0), ctypes.c_double(0)
+        nbytes = ctypes.c_uint64(0)
+        _check(self._lib.ta_timing(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(t),
+                                   ctypes.byref(nbytes)))
+        return dict(ms_sweep=a.value, ms_adjacency=b.value, ms_total=t.value, bytes_read=nbytes.value)
+
+    # -- multi-GPU views
+    def bind_accumulators(self, sums_ptr, boxes_ptr, max_label, keep=None):
+        _check(self._lib.ta_bind_accumulators(self._h, ctypes.c_void_p(int(sums_ptr) if sums_ptr else 0),
+                                              ctypes.c_void_p(int(boxes_ptr) if boxes_ptr else 0),
+                                              int(max_label)))
+        self._keep_acc = keep
+
+    def adjacency_device(self):
+        k, f, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(0)
+        _check(self._lib.ta_adjacency_device(self._h, ctypes.byref(k), ctypes.byref(f), ctypes.byref(n)))
+        return k.value, f.value, n.value
+
+    def adjacency_merge(self, keys_ptr, faces_ptr, npairs):
+        _check(self._lib.ta_adjacency_merge(self._h, ctypes.c_void_p(int(keys_ptr) if keys_ptr else 0),
+                                            ctypes.c_void_p(int(faces_ptr) if faces_ptr else 0), int(npairs)))
+
+    # -- synthetic workload + raw memory
+    def synth_voronoi(self, dev_ptr, dtype, dims, a_begin, a_count, seeds, grid, ell=None):
+        seeds = np.ascontiguousarray(seeds, dtype=np.int32)
+        g = (ctypes.c_int32 * 3)(*[int(x) for x in grid])
+        ell_arr = None if ell is None else np.ascontiguousarray(np.concatenate(ell), dtype=np.int64)
+        _check(self._lib.ta_synth_voronoi(self._h, ctypes.c_void_p(int(dev_ptr)), np.dtype(dtype).itemsize,
+                                          _i64x3(dims), int(a_begin), int(a_count), seeds.ctypes.data, g,
+                                          None if ell_arr is None else ell_arr.ctypes.data))
+
+    def malloc(self, nbytes):
+        p = ctypes.c_void_p()
+        _check(self._lib.ta_device_malloc(self._h, int(nbytes), ctypes.byref(p)))
+        return p.value
+
+    def free(self, ptr):
+        _check(self._lib.ta_device_free(self._h, ctypes.c_void_p(int(ptr))))
+
+    def d2h(self, host_array, dev_ptr):
+        _check(self._lib.ta_memcpy_d2h(self._h, host_array.ctypes.data, ctypes.c_void_p(int(dev_ptr)),
+                                       host_array.nbytes))
+
+    def h2d(self, dev_ptr, host_array):
+        a = np.ascontiguousarray(host_array)
+        _check(self._lib.ta_memcpy_h2d(self._h, ctypes.c_void_p(int(dev_ptr)), a.ctypes.data, a.nbytes))

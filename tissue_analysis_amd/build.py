@@ -1,0 +1,74 @@
+"""Build recipe for libtissue_scan.so (hipcc, gfx950 only, in-tree).
+
+    python -m tissue_analysis_amd.build [--force] [--save-temps]
+
+hipcc cross-compiles without a GPU; the built .so is git-ignored but travels with the tree.
+"""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJDIR = os.path.join(CSRC, "_obj")
+LIB = os.path.join(HERE, "libtissue_scan.so")
+SOURCES = ["ta_api.hip", "kernels_basic.hip", "kernels_sweep.hip"]
+HEADERS = ["ta_device.h", "ta_kernels.h", os.path.join("..", "..", "include", "tissue_scan.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
+         "-Wall", "-Wno-unused-function", "-DTA_BUILD"]
+
+
+def _hipcc():
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.sep not in cand or os.path.exists(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _stale(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, save_temps=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libtissue_scan.so. Returns its path."""
+    hipcc = _hipcc()
+    os.makedirs(OBJDIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    procs, objs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if save_temps:
+                cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                                cwd=OBJDIR)))
+    failed = False
+    for src, p in procs:
+        out = p.communicate()[0].decode(errors="replace")
+        if p.returncode != 0:
+            failed = True
+            sys.stderr.write("hipcc failed on %s:\n%s\n" % (src, out))
+        elif out.strip() and (verbose or save_temps):
+            print(out)
+    if failed:
+        raise RuntimeError("hipcc compilation failed")
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True))

@@ -1,0 +1,240 @@
+// kernels_basic.hip -- small gfx950 kernels around the fused sweep:
+//   init of the per-label accumulators, the per-voxel-atomics cross-check kernel (TA_OPT_IMPL=1),
+//   max-label reduction, adjacency hash collect / insert / clear, and the synthetic generator.
+#include "ta_kernels.h"
+
+namespace ta {
+
+// ------------------------------------------------------------------------------------------
+// accumulator init: sums = 0, boxes = INT32_MAX, flags = 0, cursor = 0 (one launch, 16 B stores)
+__global__ void __launch_bounds__(256) init_kernel(uint64_t* sums, int32_t* boxes, uint64_t nlabels,
+                                                   uint32_t* flags, uint32_t* cursor) {
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t nsum2 = nlabels * NSUM / 2;              // NSUM is even: ulong2 stores
+    ulonglong2* s2 = reinterpret_cast<ulonglong2*>(sums);
+    for (uint64_t i = tid; i < nsum2; i += nthreads) s2[i] = make_ulonglong2(0ull, 0ull);
+    const uint64_t nbox2 = nlabels * NBOX / 2;              // NBOX is even: int2 stores
+    int2* b2 = reinterpret_cast<int2*>(boxes);
+    for (uint64_t i = tid; i < nbox2; i += nthreads) b2[i] = make_int2(INT32_MAX, INT32_MAX);
+    if (tid < NFLAGS) flags[tid] = 0u;
+    if (tid == 0) *cursor = 0u;
+}
+
+void launch_init_accumulators(hipStream_t s, uint64_t* sums, int32_t* boxes, uint64_t nlabels,
+                              uint32_t* flags, uint32_t* pair_cursor) {
+    uint64_t work = nlabels * NSUM / 2;
+    int blocks = (int)((work + 255) / 256);
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(init_kernel, dim3(blocks), dim3(256), 0, s, sums, boxes, nlabels, flags,
+                       pair_cursor);
+}
+
+// ------------------------------------------------------------------------------------------
+// Cross-check kernel: one thread per voxel, every contribution a global atomic.  Slow by design;
+// it shares no logic with the fused sweep beyond the accumulator layout, so the two check each
+// other on the GPU (and both are checked against the CPU oracle by the tests).
+template <typename T>
+__global__ void __launch_bounds__(256) naive_kernel(SweepArgs A, uint32_t feature_mask) {
+    const int64_t plane = A.n1 * A.n2;
+    const int64_t nown = (A.n0 - A.first_owned) * plane;
+    const bool adj = feature_mask & 16u, mom2 = feature_mask & 8u;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nown;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t idx = i + A.first_owned * plane;
+        const int64_t pa = idx / plane, rem = idx - pa * plane;
+        const int64_t b = rem / A.n2, c = rem - b * A.n2;
+        const uint32_t v = load_label<T>(A.vol, idx);
+        const uint64_t ga = (uint64_t)(A.a_origin + pa - A.first_owned);
+        if (mom2) run_add_global<true>(A, v, ga, 1u, (uint64_t)b, (uint64_t)c);
+        else      run_add_global<false>(A, v, ga, 1u, (uint64_t)b, (uint64_t)c);
+        if (adj) {
+            if (pa > 0) {
+                uint32_t u = load_label<T>(A.vol, idx - plane);
+                if (u != v) pair_add_global(A.pairs, u < v ? u : v, u < v ? v : u, 1, 0, 0, A.flags);
+            }
+            if (b > 0) {
+                uint32_t u = load_label<T>(A.vol, idx - A.n2);
+                if (u != v) pair_add_global(A.pairs, u < v ? u : v, u < v ? v : u, 0, 1, 0, A.flags);
+            }
+            if (c > 0) {
+                uint32_t u = load_label<T>(A.vol, idx - 1);
+                if (u != v) pair_add_global(A.pairs, u < v ? u : v, u < v ? v : u, 0, 0, 1, A.flags);
+            }
+        }
+    }
+}
+
+void launch_naive(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask) {
+    const int64_t nown = (a.n0 - a.first_owned) * a.n1 * a.n2;
+    if (nown <= 0) return;
+    int64_t blocks = (nown + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (itemsize == 2)
+        hipLaunchKernelGGL(naive_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, a, feature_mask);
+    else
+        hipLaunchKernelGGL(naive_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s, a, feature_mask);
+}
+
+// ------------------------------------------------------------------------------------------
+// max label: 16-byte loads, wave max via DPP-free shuffles, one atomicMax per wave
+template <typename T>
+__global__ void __launch_bounds__(256) max_label_kernel(const T* vol, uint64_t nvox, uint32_t* out) {
+    constexpr int VEC = 16 / sizeof(T);
+    const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
+    uint32_t m = 0;
+    const uint64_t nvec = ((reinterpret_cast<uintptr_t>(vol) & 15) == 0) ? nvox / VEC : 0;
+    const uint4* v4 = reinterpret_cast<const uint4*>(vol);
+    for (uint64_t i = tid; i < nvec; i += nthreads) {
+        uint4 x = v4[i];
+        if (sizeof(T) == 4) {
+            m = max(m, max(max(x.x, x.y), max(x.z, x.w)));
+        } else {
+            m = max(m, max(max(x.x & 0xffffu, x.x >> 16), max(x.y & 0xffffu, x.y >> 16)));
+            m = max(m, max(max(x.z & 0xffffu, x.z >> 16), max(x.w & 0xffffu, x.w >> 16)));
+        }
+    }
+    for (uint64_t i = nvec * VEC + tid; i < nvox; i += nthreads) m = max(m, (uint32_t)vol[i]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
+void launch_max_label(hipStream_t s, const void* vol, int itemsize, uint64_t nvox, uint32_t* out_dev) {
+    hipMemsetAsync(out_dev, 0, sizeof(uint32_t), s);
+    if (nvox == 0) return;
+    uint64_t blocks = (nvox / (16 / itemsize) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    if (itemsize == 2)
+        hipLaunchKernelGGL(max_label_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           (const uint16_t*)vol, nvox, out_dev);
+    else
+        hipLaunchKernelGGL(max_label_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           (const uint32_t*)vol, nvox, out_dev);
+}
+
+// ------------------------------------------------------------------------------------------
+// adjacency hash: collect (and self-clean), insert, clear
+__global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64_t* out_keys,
+                                                            uint64_t* out_faces, uint32_t* cursor) {
+    const uint64_t cap = (uint64_t)pt.mask + 1;
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < cap;
+         h += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = pt.keys[h];
+        if (k != EMPTY_KEY) {
+            const uint32_t i = atomicAdd(cursor, 1u);        // wave-aggregated by the compiler
+            out_keys[i] = k;
+            out_faces[3ull * i + 0] = pt.faces[3 * h + 0];
+            out_faces[3ull * i + 1] = pt.faces[3 * h + 1];
+            out_faces[3ull * i + 2] = pt.faces[3 * h + 2];
+            pt.keys[h] = EMPTY_KEY;                          // leave the table clean for the next call
+            pt.faces[3 * h + 0] = 0; pt.faces[3 * h + 1] = 0; pt.faces[3 * h + 2] = 0;
+        }
+    }
+}
+
+void launch_pairs_collect(hipStream_t s, const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces,
+                          uint32_t* cursor) {
+    uint64_t cap = (uint64_t)pt.mask + 1;
+    uint64_t blocks = (cap + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pairs_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pt, out_keys,
+                       out_faces, cursor);
+}
+
+__global__ void __launch_bounds__(256) pairs_insert_kernel(PairTable pt, const uint64_t* keys,
+                                                           const uint64_t* faces, uint64_t n,
+                                                           uint32_t* flags) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t k = keys[i];
+        if (k == EMPTY_KEY) continue;                        // padding of gathered lists
+        pair_add_global(pt, (uint32_t)(k >> 32), (uint32_t)k, faces[3 * i], faces[3 * i + 1],
+                        faces[3 * i + 2], flags);
+    }
+}
+
+void launch_pairs_insert(hipStream_t s, const PairTable& pt, const uint64_t* keys, const uint64_t* faces,
+                         uint64_t n, uint32_t* flags) {
+    if (n == 0) return;
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pairs_insert_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pt, keys, faces, n,
+                       flags);
+}
+
+__global__ void __launch_bounds__(256) pairs_clear_kernel(PairTable pt) {
+    const uint64_t cap = (uint64_t)pt.mask + 1;
+    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < cap;
+         h += (uint64_t)gridDim.x * blockDim.x) {
+        pt.keys[h] = EMPTY_KEY;
+        pt.faces[3 * h + 0] = 0; pt.faces[3 * h + 1] = 0; pt.faces[3 * h + 2] = 0;
+    }
+}
+
+void launch_pairs_clear(hipStream_t s, const PairTable& pt) {
+    uint64_t cap = (uint64_t)pt.mask + 1;
+    uint64_t blocks = (cap + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pairs_clear_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pt);
+}
+
+// ------------------------------------------------------------------------------------------
+// Synthetic jittered-grid Voronoi tissue (tissue_analysis_amd/synth.py is the definition).
+template <typename T>
+__global__ void __launch_bounds__(256) synth_kernel(T* out, int64_t d0, int64_t d1, int64_t d2,
+                                                    int64_t a_begin, int64_t a_count,
+                                                    const int32_t* seeds, int g0, int g1, int g2,
+                                                    const int64_t* ell) {
+    const int64_t n = a_count * d1 * d2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t pa = i / (d1 * d2), rem = i - pa * d1 * d2;
+        const int x0 = (int)(a_begin + pa), x1 = (int)(rem / d2), x2 = (int)(rem - (rem / d2) * d2);
+        uint32_t label;
+        bool inside = true;
+        if (ell) inside = (ell[x0] + ell[d0 + x1] + ell[d0 + d1 + x2]) <= (1ll << 24);
+        if (!inside) {
+            label = 1u;
+        } else {
+            const int i0 = (int)(((int64_t)x0 * g0) / d0), i1 = (int)(((int64_t)x1 * g1) / d1),
+                      i2 = (int)(((int64_t)x2 * g2) / d2);
+            int64_t best_d = INT64_MAX;
+            uint32_t best_l = 0xFFFFFFFFu;
+            for (int j0 = max(i0 - 2, 0); j0 <= min(i0 + 2, g0 - 1); ++j0)
+                for (int j1 = max(i1 - 2, 0); j1 <= min(i1 + 2, g1 - 1); ++j1)
+                    for (int j2 = max(i2 - 2, 0); j2 <= min(i2 + 2, g2 - 1); ++j2) {
+                        const int cell = (j0 * g1 + j1) * g2 + j2;
+                        const int64_t e0 = x0 - seeds[3 * cell + 0], e1 = x1 - seeds[3 * cell + 1],
+                                      e2 = x2 - seeds[3 * cell + 2];
+                        const int64_t d = e0 * e0 + e1 * e1 + e2 * e2;
+                        const uint32_t l = (uint32_t)cell + 2u;
+                        if (d < best_d || (d == best_d && l < best_l)) { best_d = d; best_l = l; }
+                    }
+            label = best_l;
+        }
+        out[i] = (T)label;
+    }
+}
+
+void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3], int64_t a_begin,
+                  int64_t a_count, const int32_t* seeds_dev, const int32_t grid[3],
+                  const int64_t* ell_dev) {
+    const int64_t n = a_count * dims[1] * dims[2];
+    if (n <= 0) return;
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (itemsize == 2)
+        hipLaunchKernelGGL(synth_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           (uint16_t*)out, dims[0], dims[1], dims[2], a_begin, a_count, seeds_dev,
+                           grid[0], grid[1], grid[2], ell_dev);
+    else
+        hipLaunchKernelGGL(synth_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s,
+                           (uint32_t*)out, dims[0], dims[1], dims[2], a_begin, a_count, seeds_dev,
+                           grid[0], grid[1], grid[2], ell_dev);
+}
+
+}  // namespace ta

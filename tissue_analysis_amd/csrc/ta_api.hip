@@ -1,0 +1,627 @@
+// ta_api.hip -- the C ABI of include/tissue_scan.h on top of the gfx950 kernels.
+#include "../../include/tissue_scan.h"
+#include "ta_kernels.h"
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <numeric>
+#include <string>
+#include <vector>
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define TA_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess)                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? TA_ENOMEM : TA_EHIP, "%s: %s (%s:%d)",  \
+                        #expr, hipGetErrorString(e_), __FILE__, __LINE__);                   \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    uint64_t bytes = 0;
+    int reserve(uint64_t need) {
+        if (need <= bytes) return TA_OK;
+        if (p) { (void)hipFree(p); p = nullptr; bytes = 0; }
+        if (hipMalloc(&p, need ? need : 16) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            return fail(TA_ENOMEM, "hipMalloc of %llu bytes failed", (unsigned long long)need);
+        }
+        bytes = need;
+        return TA_OK;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
+};
+
+}  // namespace
+
+struct ta_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+
+    // resident volume
+    const void* vol = nullptr;       // device pointer (owned_vol.p or adopted)
+    DevBuf owned_vol;
+    int itemsize = 0;
+    int64_t mdims[3] = {0, 0, 0};    // buffer dims in memory-axis order
+    int perm[3] = {0, 1, 2};         // perm[k] = array axis of memory axis k
+    int64_t a_origin = 0;
+    int first_owned = 0;
+
+    // accumulators
+    DevBuf own_sums, own_boxes;
+    uint64_t* sums = nullptr;
+    int32_t* boxes = nullptr;
+    bool bound = false;
+    uint32_t bound_max_label = 0;
+    uint32_t max_label = 0;
+
+    // adjacency
+    DevBuf pkeys, pfaces, out_keys, out_faces, small;   // small: flags[NFLAGS] | cursor | maxlabel
+    int pair_log2 = 0;                                  // current table log2 capacity
+    int opt_pair_log2 = 0;
+    bool table_clean = false;
+    uint32_t* h_small = nullptr;                        // pinned mirror of `small`
+
+    // options / state
+    int impl = 0;
+    int tile_planes = 0;
+    uint32_t feature_mask = 0;
+    bool extracted = false, checked = false;
+    int64_t npairs = 0;
+    std::vector<uint64_t> h_keys, h_faces;              // sorted host copy for ta_adjacency_get
+    bool host_pairs_ready = false;
+};
+
+namespace {
+
+constexpr int SMALL_WORDS = ta::NFLAGS + 2;   // flags, cursor, max label
+
+uint32_t* flags_dev(ta_ctx* c) { return (uint32_t*)c->small.p; }
+uint32_t* cursor_dev(ta_ctx* c) { return (uint32_t*)c->small.p + ta::NFLAGS; }
+uint32_t* maxlab_dev(ta_ctx* c) { return (uint32_t*)c->small.p + ta::NFLAGS + 1; }
+
+int use_device(ta_ctx* c) {
+    TA_HIP(hipSetDevice(c->device));
+    return TA_OK;
+}
+
+int ensure_pair_table(ta_ctx* c, int log2cap) {
+    if (c->pair_log2 == log2cap && c->pkeys.p) return TA_OK;
+    const uint64_t cap = 1ull << log2cap;
+    int rc;
+    if ((rc = c->pkeys.reserve(cap * 8)) != TA_OK) return rc;
+    if ((rc = c->pfaces.reserve(cap * 24)) != TA_OK) return rc;
+    if ((rc = c->out_keys.reserve(cap * 8)) != TA_OK) return rc;
+    if ((rc = c->out_faces.reserve(cap * 24)) != TA_OK) return rc;
+    c->pair_log2 = log2cap;
+    c->table_clean = false;
+    return TA_OK;
+}
+
+ta::PairTable pair_table(ta_ctx* c) {
+    ta::PairTable pt;
+    pt.keys = (uint64_t*)c->pkeys.p;
+    pt.faces = (uint64_t*)c->pfaces.p;
+    pt.mask = (uint32_t)((1ull << c->pair_log2) - 1);
+    return pt;
+}
+
+int auto_pair_log2(uint32_t max_label) {
+    uint64_t want = 16ull * ((uint64_t)max_label + 1);
+    int l = 16;
+    while ((1ull << l) < want && l < 28) ++l;
+    return l;
+}
+
+// One full extraction pass on the stream (no host sync).
+int run_extract(ta_ctx* c) {
+    const uint64_t nlabels = (uint64_t)c->max_label + 1;
+    ta::SweepArgs a;
+    a.vol = c->vol;
+    a.n0 = c->mdims[0]; a.n1 = c->mdims[1]; a.n2 = c->mdims[2];
+    a.a_origin = c->a_origin;
+    a.first_owned = c->first_owned;
+    a.tile_planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes();
+    if (a.tile_planes > 4096) a.tile_planes = 4096;
+    a.vec_ok = (((uintptr_t)c->vol & 15) == 0) && ((a.n2 * c->itemsize) % 16 == 0);
+    a.max_label = c->max_label;
+    a.sums = c->sums;
+    a.boxes = c->boxes;
+    a.pairs = pair_table(c);
+    a.flags = flags_dev(c);
+
+    const bool adj = c->feature_mask & TA_F_ADJACENCY;
+    TA_HIP(hipEventRecord(c->ev[0], c->stream));
+    if (adj && !c->table_clean) {
+        ta::launch_pairs_clear(c->stream, a.pairs);
+        c->table_clean = true;
+    }
+    ta::launch_init_accumulators(c->stream, c->sums, c->boxes, nlabels, flags_dev(c), cursor_dev(c));
+    TA_HIP(hipEventRecord(c->ev[1], c->stream));
+    if (c->impl == 1) ta::launch_naive(c->stream, a, c->itemsize, c->feature_mask);
+    else              ta::launch_sweep(c->stream, a, c->itemsize, c->feature_mask);
+    TA_HIP(hipEventRecord(c->ev[2], c->stream));
+    if (adj)
+        ta::launch_pairs_collect(c->stream, a.pairs, (uint64_t*)c->out_keys.p, (uint64_t*)c->out_faces.p,
+                                 cursor_dev(c));
+    TA_HIP(hipEventRecord(c->ev[3], c->stream));
+    TA_HIP(hipMemcpyAsync(c->h_small, c->small.p, SMALL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                          c->stream));
+    TA_HIP(hipGetLastError());
+    return TA_OK;
+}
+
+// Drain the stream and validate the flags of the last pass; grows the adjacency table and
+// re-runs when it overflowed.
+int finish_extract(ta_ctx* c) {
+    if (!c->extracted) return fail(TA_EINVAL, "no extraction has been run on this context");
+    if (c->checked) return TA_OK;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        TA_HIP(hipStreamSynchronize(c->stream));
+        if (c->h_small[ta::FLAG_RANGE])
+            return fail(TA_ERANGE, "the volume holds a label above max_label=%u", c->max_label);
+        if (!c->h_small[ta::FLAG_PAIR_OVERFLOW]) {
+            c->npairs = (c->feature_mask & TA_F_ADJACENCY) ? (int64_t)c->h_small[ta::NFLAGS] : 0;
+            c->checked = true;
+            return TA_OK;
+        }
+        if (c->pair_log2 >= 30) break;
+        int rc = ensure_pair_table(c, c->pair_log2 + 2);
+        if (rc != TA_OK) return rc;
+        if ((rc = run_extract(c)) != TA_OK) return rc;
+    }
+    return fail(TA_ECAPACITY, "adjacency table overflow at 2^%d slots", c->pair_log2);
+}
+
+}  // namespace
+
+extern "C" {
+
+TA_API int ta_version(void) { return TA_ABI_VERSION; }
+
+TA_API const char* ta_last_error(void) { return g_err.c_str(); }
+
+TA_API int ta_device_count(int* count) {
+    if (!count) return fail(TA_EINVAL, "count is NULL");
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); n = 0; }
+    *count = n;
+    return TA_OK;
+}
+
+TA_API int ta_ctx_create(int device_id, ta_ctx** out) {
+    if (!out) return fail(TA_EINVAL, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        (void)hipGetLastError();
+        return fail(TA_ENODEVICE, "no HIP device visible (libtissue_scan needs an MI355X / gfx950 GPU)");
+    }
+    if (device_id < 0 || device_id >= n) return fail(TA_EINVAL, "device_id %d out of range [0,%d)", device_id, n);
+    ta_ctx* c = new (std::nothrow) ta_ctx();
+    if (!c) return fail(TA_ENOMEM, "out of host memory");
+    c->device = device_id;
+    TA_HIP(hipSetDevice(device_id));
+    TA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    c->own_stream = true;
+    for (auto& e : c->ev) TA_HIP(hipEventCreate(&e));
+    int rc = c->small.reserve(SMALL_WORDS * sizeof(uint32_t));
+    if (rc != TA_OK) return rc;
+    TA_HIP(hipHostMalloc((void**)&c->h_small, SMALL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    memset(c->h_small, 0, SMALL_WORDS * sizeof(uint32_t));
+    *out = c;
+    return TA_OK;
+}
+
+TA_API int ta_ctx_destroy(ta_ctx* c) {
+    if (!c) return TA_OK;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    c->owned_vol.release(); c->own_sums.release(); c->own_boxes.release();
+    c->pkeys.release(); c->pfaces.release(); c->out_keys.release(); c->out_faces.release();
+    c->small.release();
+    if (c->h_small) (void)hipHostFree(c->h_small);
+    for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+    return TA_OK;
+}
+
+TA_API int ta_ctx_set_stream(ta_ctx* c, void* hip_stream) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    if (c->stream) TA_HIP(hipStreamSynchronize(c->stream));
+    if (c->own_stream && c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
+    if (hip_stream) {
+        c->stream = (hipStream_t)hip_stream;
+        c->own_stream = false;
+    } else {
+        TA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+    }
+    return TA_OK;
+}
+
+TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    switch (key) {
+        case TA_OPT_IMPL:
+            if (value != 0 && value != 1) return fail(TA_EINVAL, "TA_OPT_IMPL must be 0 or 1");
+            c->impl = (int)value; return TA_OK;
+        case TA_OPT_TILE_PLANES:
+            if (value < 0 || value > 4096) return fail(TA_EINVAL, "TA_OPT_TILE_PLANES must be in [0,4096]");
+            c->tile_planes = (int)value; return TA_OK;
+        case TA_OPT_PAIR_SLOTS:
+            if (value != 0 && (value < 4 || value > 30)) return fail(TA_EINVAL, "TA_OPT_PAIR_SLOTS must be 0 or in [4,30]");
+            c->opt_pair_log2 = (int)value; return TA_OK;
+        default:
+            return fail(TA_EINVAL, "unknown option key %d", key);
+    }
+}
+
+TA_API int ta_ctx_synchronize(ta_ctx* c) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    TA_HIP(hipStreamSynchronize(c->stream));
+    return TA_OK;
+}
+
+TA_API int ta_volume_set(ta_ctx* c, const void* host_ptr, int itemsize, const int64_t dims[3],
+                  const int64_t strides_bytes[3]) {
+    if (!c || !host_ptr || !dims) return fail(TA_EINVAL, "NULL argument");
+    if (itemsize != 2 && itemsize != 4) return fail(TA_EINVAL, "itemsize must be 2 (uint16) or 4 (uint32)");
+    for (int d = 0; d < 3; ++d)
+        if (dims[d] <= 0 || dims[d] > (1ll << 30)) return fail(TA_EINVAL, "dims[%d]=%lld out of range", d, (long long)dims[d]);
+    int perm[3] = {0, 1, 2};
+    if (strides_bytes) {
+        // memory order = axes by decreasing stride (size-1 axes are layout-neutral: keep them first)
+        std::stable_sort(perm, perm + 3, [&](int x, int y) {
+            const int64_t sx = dims[x] == 1 ? INT64_MAX : strides_bytes[x];
+            const int64_t sy = dims[y] == 1 ? INT64_MAX : strides_bytes[y];
+            return sx > sy;
+        });
+        int64_t expect = itemsize;
+        for (int k = 2; k >= 0; --k) {
+            const int ax = perm[k];
+            if (dims[ax] != 1 && strides_bytes[ax] != expect)
+                return fail(TA_EINVAL, "strides do not describe a dense permuted layout (axis %d: stride %lld, expected %lld)",
+                            ax, (long long)strides_bytes[ax], (long long)expect);
+            expect *= dims[ax];
+        }
+    }
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t bytes = (uint64_t)dims[0] * dims[1] * dims[2] * itemsize;
+    TA_HIP(hipStreamSynchronize(c->stream));
+    if ((rc = c->owned_vol.reserve(bytes)) != TA_OK) return rc;
+    TA_HIP(hipMemcpyAsync(c->owned_vol.p, host_ptr, bytes, hipMemcpyHostToDevice, c->stream));
+    TA_HIP(hipStreamSynchronize(c->stream));   // the host buffer may be freed after return
+    c->vol = c->owned_vol.p;
+    c->itemsize = itemsize;
+    for (int k = 0; k < 3; ++k) { c->perm[k] = perm[k]; c->mdims[k] = dims[perm[k]]; }
+    c->a_origin = 0;
+    c->first_owned = 0;
+    c->extracted = c->checked = false;
+    return TA_OK;
+}
+
+TA_API int ta_volume_set_device(ta_ctx* c, const void* dev_ptr, int itemsize, const int64_t buf_dims[3],
+                         int64_t a0_origin, int has_low_halo) {
+    if (!c || !dev_ptr || !buf_dims) return fail(TA_EINVAL, "NULL argument");
+    if (itemsize != 2 && itemsize != 4) return fail(TA_EINVAL, "itemsize must be 2 (uint16) or 4 (uint32)");
+    for (int d = 0; d < 3; ++d)
+        if (buf_dims[d] <= 0 || buf_dims[d] > (1ll << 30)) return fail(TA_EINVAL, "buf_dims[%d]=%lld out of range", d, (long long)buf_dims[d]);
+    if (has_low_halo && buf_dims[0] < 2) return fail(TA_EINVAL, "a slab with a halo needs at least 2 planes");
+    if (a0_origin < 0) return fail(TA_EINVAL, "a0_origin must be >= 0");
+    if (((uintptr_t)dev_ptr % itemsize) != 0) return fail(TA_EINVAL, "device pointer is not aligned to the label type");
+    c->vol = dev_ptr;
+    c->itemsize = itemsize;
+    for (int k = 0; k < 3; ++k) { c->perm[k] = k; c->mdims[k] = buf_dims[k]; }
+    c->a_origin = a0_origin;
+    c->first_owned = has_low_halo ? 1 : 0;
+    c->extracted = c->checked = false;
+    return TA_OK;
+}
+
+TA_API int ta_volume_max_label(ta_ctx* c, uint32_t* max_label) {
+    if (!c || !max_label) return fail(TA_EINVAL, "NULL argument");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t nvox = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2];
+    ta::launch_max_label(c->stream, c->vol, c->itemsize, nvox, maxlab_dev(c));
+    uint32_t v = 0;
+    TA_HIP(hipMemcpyAsync(&v, maxlab_dev(c), sizeof(v), hipMemcpyDeviceToHost, c->stream));
+    TA_HIP(hipStreamSynchronize(c->stream));
+    TA_HIP(hipGetLastError());
+    *max_label = v;
+    return TA_OK;
+}
+
+TA_API int ta_bind_accumulators(ta_ctx* c, void* sums_dev, void* boxes_dev, uint32_t max_label) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if ((sums_dev == nullptr) != (boxes_dev == nullptr)) return fail(TA_EINVAL, "bind both buffers or neither");
+    if (sums_dev && (((uintptr_t)sums_dev & 15) || ((uintptr_t)boxes_dev & 7)))
+        return fail(TA_EINVAL, "bound accumulators must be 16-byte (sums) / 8-byte (boxes) aligned");
+    c->bound = sums_dev != nullptr;
+    c->bound_max_label = max_label;
+    if (c->bound) { c->sums = (uint64_t*)sums_dev; c->boxes = (int32_t*)boxes_dev; }
+    else { c->sums = nullptr; c->boxes = nullptr; }
+    c->extracted = c->checked = false;
+    return TA_OK;
+}
+
+TA_API int ta_extract(ta_ctx* c, uint32_t feature_mask, uint32_t max_label) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    if (feature_mask == 0 || (feature_mask & ~TA_F_ALL)) return fail(TA_EINVAL, "bad feature mask 0x%x", feature_mask);
+    if (max_label >= (1u << 28)) return fail(TA_EINVAL, "max_label %u too large for dense per-label rows", max_label);
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    {   // exactness guard: every u64 sum must stay below 2^64
+        const long double g0 = (long double)(c->a_origin + c->mdims[0]), nv = (long double)c->mdims[0] * c->mdims[1] * c->mdims[2];
+        const long double gm = std::max(g0, std::max((long double)c->mdims[1], (long double)c->mdims[2]));
+        if (nv * gm * gm >= 1.8e19L) return fail(TA_EINVAL, "volume too large for exact 64-bit second moments");
+    }
+    const uint64_t nlabels = (uint64_t)max_label + 1;
+    if (c->bound) {
+        if (c->bound_max_label != max_label)
+            return fail(TA_EINVAL, "bound accumulators are sized for max_label=%u, not %u", c->bound_max_label, max_label);
+    } else {
+        if ((rc = c->own_sums.reserve(nlabels * ta::NSUM * 8)) != TA_OK) return rc;
+        if ((rc = c->own_boxes.reserve(nlabels * ta::NBOX * 4)) != TA_OK) return rc;
+        c->sums = (uint64_t*)c->own_sums.p;
+        c->boxes = (int32_t*)c->own_boxes.p;
+    }
+    c->max_label = max_label;
+    c->feature_mask = feature_mask;
+    {
+        const bool adj = feature_mask & TA_F_ADJACENCY;
+        int want = c->opt_pair_log2 ? c->opt_pair_log2
+                                    : std::max(c->pkeys.p ? c->pair_log2 : 4, adj ? auto_pair_log2(max_label) : 4);
+        if ((rc = ensure_pair_table(c, want)) != TA_OK) return rc;
+    }
+    c->extracted = true;
+    c->checked = false;
+    c->host_pairs_ready = false;
+    return run_extract(c);
+}
+
+TA_API int ta_get_labels(ta_ctx* c, uint64_t* count, int32_t* bbox, uint64_t* sum1, uint64_t* sum2) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    if ((rc = finish_extract(c)) != TA_OK) return rc;
+    const uint64_t n = (uint64_t)c->max_label + 1;
+    std::vector<uint64_t> hs;
+    std::vector<int32_t> hb;
+    try {
+        if (count || sum1 || sum2) hs.resize(n * ta::NSUM);
+        if (bbox) hb.resize(n * ta::NBOX);
+    } catch (...) { return fail(TA_ENOMEM, "out of host memory"); }
+    if (!hs.empty()) TA_HIP(hipMemcpyAsync(hs.data(), c->sums, hs.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    if (!hb.empty()) TA_HIP(hipMemcpyAsync(hb.data(), c->boxes, hb.size() * 4, hipMemcpyDeviceToHost, c->stream));
+    TA_HIP(hipStreamSynchronize(c->stream));
+    // second-moment slot of an (array axis, array axis) pair
+    auto pair_slot = [](int x, int y) { if (x > y) std::swap(x, y); return x == 0 ? y : (x == 1 ? 2 + y : 5); };
+    static const int mem_pair[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+    for (uint64_t l = 0; l < n; ++l) {
+        if (count) count[l] = hs[l * ta::NSUM];
+        if (sum1) for (int k = 0; k < 3; ++k) sum1[l * 3 + c->perm[k]] = hs[l * ta::NSUM + 1 + k];
+        if (sum2) for (int q = 0; q < 6; ++q)
+            sum2[l * 6 + pair_slot(c->perm[mem_pair[q][0]], c->perm[mem_pair[q][1]])] = hs[l * ta::NSUM + 4 + q];
+        if (bbox) {
+            const bool present = hb[l * 6] != INT32_MAX;
+            for (int k = 0; k < 3; ++k) {
+                bbox[l * 6 + c->perm[k]] = present ? hb[l * 6 + k] : -1;
+                bbox[l * 6 + 3 + c->perm[k]] = present ? (-hb[l * 6 + 3 + k] + 1) : -1;
+            }
+        }
+    }
+    return TA_OK;
+}
+
+TA_API int ta_adjacency_size(ta_ctx* c, int64_t* npairs) {
+    if (!c || !npairs) return fail(TA_EINVAL, "NULL argument");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    if ((rc = finish_extract(c)) != TA_OK) return rc;
+    *npairs = c->npairs;
+    return TA_OK;
+}
+
+TA_API int ta_adjacency_get(ta_ctx* c, uint32_t* lo, uint32_t* hi, uint64_t* faces) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    if ((rc = finish_extract(c)) != TA_OK) return rc;
+    const uint64_t n = (uint64_t)c->npairs;
+    if (!c->host_pairs_ready) {
+        std::vector<uint64_t> k, f;
+        std::vector<uint32_t> order;
+        try { k.resize(n); f.resize(n * 3); order.resize(n); c->h_keys.resize(n); c->h_faces.resize(n * 3); }
+        catch (...) { return fail(TA_ENOMEM, "out of host memory"); }
+        if (n) {
+            TA_HIP(hipMemcpyAsync(k.data(), c->out_keys.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+            TA_HIP(hipMemcpyAsync(f.data(), c->out_faces.p, n * 24, hipMemcpyDeviceToHost, c->stream));
+            TA_HIP(hipStreamSynchronize(c->stream));
+        }
+        std::iota(order.begin(), order.end(), 0u);
+        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return k[x] < k[y]; });
+        for (uint64_t i = 0; i < n; ++i) {
+            c->h_keys[i] = k[order[i]];
+            for (int d = 0; d < 3; ++d) c->h_faces[3 * i + d] = f[3ull * order[i] + d];
+        }
+        c->host_pairs_ready = true;
+    }
+    for (uint64_t i = 0; i < n; ++i) {
+        if (lo) lo[i] = (uint32_t)(c->h_keys[i] >> 32);
+        if (hi) hi[i] = (uint32_t)(c->h_keys[i] & 0xffffffffu);
+        if (faces) for (int k = 0; k < 3; ++k) faces[3 * i + c->perm[k]] = c->h_faces[3 * i + k];
+    }
+    return TA_OK;
+}
+
+TA_API int ta_timing(ta_ctx* c, double* ms_sweep, double* ms_adjacency, double* ms_total, uint64_t* bytes_read) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if (!c->extracted) return fail(TA_EINVAL, "no extraction has been run on this context");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    TA_HIP(hipEventSynchronize(c->ev[3]));
+    float a = 0, b = 0, t = 0;
+    TA_HIP(hipEventElapsedTime(&a, c->ev[1], c->ev[2]));
+    TA_HIP(hipEventElapsedTime(&b, c->ev[2], c->ev[3]));
+    TA_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
+    if (ms_sweep) *ms_sweep = a;
+    if (ms_adjacency) *ms_adjacency = b;
+    if (ms_total) *ms_total = t;
+    if (bytes_read)
+        *bytes_read = (uint64_t)(c->mdims[0] - c->first_owned) * c->mdims[1] * c->mdims[2] * c->itemsize;
+    return TA_OK;
+}
+
+TA_API int ta_accumulators_device(ta_ctx* c, void** sums_dev, void** boxes_dev, uint32_t* max_label) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if (!c->extracted) return fail(TA_EINVAL, "no extraction has been run on this context");
+    if (sums_dev) *sums_dev = c->sums;
+    if (boxes_dev) *boxes_dev = c->boxes;
+    if (max_label) *max_label = c->max_label;
+    return TA_OK;
+}
+
+TA_API int ta_adjacency_device(ta_ctx* c, void** keys_dev, void** faces_dev, int64_t* npairs) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    if ((rc = finish_extract(c)) != TA_OK) return rc;
+    if (keys_dev) *keys_dev = c->out_keys.p;
+    if (faces_dev) *faces_dev = c->out_faces.p;
+    if (npairs) *npairs = c->npairs;
+    return TA_OK;
+}
+
+TA_API int ta_adjacency_merge(ta_ctx* c, const void* keys_dev, const void* faces_dev, int64_t npairs) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if (npairs < 0 || (npairs > 0 && (!keys_dev || !faces_dev))) return fail(TA_EINVAL, "bad pair list");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    if ((rc = finish_extract(c)) != TA_OK) return rc;
+    if (!(c->feature_mask & TA_F_ADJACENCY)) return fail(TA_EINVAL, "the last extraction did not request adjacency");
+    // local list (already collected, so the table is clean) + foreign list -> table -> collect again
+    ta::PairTable pt = pair_table(c);
+    DevBuf local_k, local_f;
+    const uint64_t nl = (uint64_t)c->npairs;
+    if ((rc = local_k.reserve(nl * 8 + 8)) != TA_OK) return rc;
+    if ((rc = local_f.reserve(nl * 24 + 8)) != TA_OK) { local_k.release(); return rc; }
+    hipError_t e = hipSuccess;
+    if (nl) {
+        e = hipMemcpyAsync(local_k.p, c->out_keys.p, nl * 8, hipMemcpyDeviceToDevice, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(local_f.p, c->out_faces.p, nl * 24, hipMemcpyDeviceToDevice, c->stream);
+    }
+    if (e == hipSuccess) e = hipMemsetAsync(c->small.p, 0, SMALL_WORDS * sizeof(uint32_t), c->stream);
+    if (e != hipSuccess) { local_k.release(); local_f.release(); return fail(TA_EHIP, "merge staging: %s", hipGetErrorString(e)); }
+    ta::launch_pairs_insert(c->stream, pt, (const uint64_t*)local_k.p, (const uint64_t*)local_f.p, nl, flags_dev(c));
+    ta::launch_pairs_insert(c->stream, pt, (const uint64_t*)keys_dev, (const uint64_t*)faces_dev, (uint64_t)npairs, flags_dev(c));
+    ta::launch_pairs_collect(c->stream, pt, (uint64_t*)c->out_keys.p, (uint64_t*)c->out_faces.p, cursor_dev(c));
+    e = hipMemcpyAsync(c->h_small, c->small.p, SMALL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    local_k.release(); local_f.release();
+    if (e != hipSuccess) return fail(TA_EHIP, "merge: %s", hipGetErrorString(e));
+    if (c->h_small[ta::FLAG_PAIR_OVERFLOW])
+        return fail(TA_ECAPACITY, "adjacency table overflow while merging (2^%d slots); raise TA_OPT_PAIR_SLOTS", c->pair_log2);
+    c->npairs = (int64_t)c->h_small[ta::NFLAGS];
+    c->host_pairs_ready = false;
+    return TA_OK;
+}
+
+TA_API int ta_synth_voronoi(ta_ctx* c, void* dev_out, int itemsize, const int64_t dims[3], int64_t a_begin,
+                     int64_t a_count, const int32_t* seeds, const int32_t grid[3], const int64_t* ell) {
+    if (!c || !dev_out || !dims || !seeds || !grid) return fail(TA_EINVAL, "NULL argument");
+    if (itemsize != 2 && itemsize != 4) return fail(TA_EINVAL, "itemsize must be 2 or 4");
+    if (a_begin < 0 || a_count < 0 || a_begin + a_count > dims[0]) return fail(TA_EINVAL, "plane range out of bounds");
+    const int64_t ncell = (int64_t)grid[0] * grid[1] * grid[2];
+    if (ncell <= 0) return fail(TA_EINVAL, "empty seed grid");
+    if (itemsize == 2 && ncell + 1 > 65535) return fail(TA_EINVAL, "uint16 cannot hold %lld labels", (long long)ncell + 1);
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    DevBuf dseeds, dell;
+    if ((rc = dseeds.reserve((uint64_t)ncell * 12)) != TA_OK) return rc;
+    hipError_t e = hipMemcpyAsync(dseeds.p, seeds, (uint64_t)ncell * 12, hipMemcpyHostToDevice, c->stream);
+    const uint64_t nell = (uint64_t)(dims[0] + dims[1] + dims[2]);
+    if (e == hipSuccess && ell) {
+        if ((rc = dell.reserve(nell * 8)) != TA_OK) { dseeds.release(); return rc; }
+        e = hipMemcpyAsync(dell.p, ell, nell * 8, hipMemcpyHostToDevice, c->stream);
+    }
+    if (e == hipSuccess) {
+        ta::launch_synth(c->stream, dev_out, itemsize, dims, a_begin, a_count, (const int32_t*)dseeds.p, grid,
+                         ell ? (const int64_t*)dell.p : nullptr);
+        e = hipStreamSynchronize(c->stream);
+    }
+    dseeds.release(); dell.release();
+    if (e != hipSuccess) return fail(TA_EHIP, "ta_synth_voronoi: %s", hipGetErrorString(e));
+    TA_HIP(hipGetLastError());
+    return TA_OK;
+}
+
+TA_API int ta_device_malloc(ta_ctx* c, uint64_t bytes, void** dev_ptr) {
+    if (!c || !dev_ptr) return fail(TA_EINVAL, "NULL argument");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    *dev_ptr = nullptr;
+    if (hipMalloc(dev_ptr, bytes ? bytes : 16) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(TA_ENOMEM, "hipMalloc of %llu bytes failed", (unsigned long long)bytes);
+    }
+    return TA_OK;
+}
+
+TA_API int ta_device_free(ta_ctx* c, void* dev_ptr) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    TA_HIP(hipStreamSynchronize(c->stream));
+    if (dev_ptr) TA_HIP(hipFree(dev_ptr));
+    return TA_OK;
+}
+
+TA_API int ta_memcpy_d2h(ta_ctx* c, void* host_dst, const void* dev_src, uint64_t bytes) {
+    if (!c || (bytes && (!host_dst || !dev_src))) return fail(TA_EINVAL, "NULL argument");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    TA_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, c->stream));
+    TA_HIP(hipStreamSynchronize(c->stream));
+    return TA_OK;
+}
+
+TA_API int ta_memcpy_h2d(ta_ctx* c, void* dev_dst, const void* host_src, uint64_t bytes) {
+    if (!c || (bytes && (!dev_dst || !host_src))) return fail(TA_EINVAL, "NULL argument");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    TA_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, c->stream));
+    TA_HIP(hipStreamSynchronize(c->stream));
+    return TA_OK;
+}
+
+}  // extern "C"

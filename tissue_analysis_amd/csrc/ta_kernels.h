@@ -1,0 +1,25 @@
+// ta_kernels.h -- host-callable launchers implemented in the kernels_*.hip files.
+#pragma once
+#include "ta_device.h"
+
+namespace ta {
+
+// kernels_basic.hip
+void launch_init_accumulators(hipStream_t s, uint64_t* sums, int32_t* boxes, uint64_t nlabels,
+                              uint32_t* flags, uint32_t* pair_cursor);
+void launch_naive(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);
+void launch_max_label(hipStream_t s, const void* vol, int itemsize, uint64_t nvox, uint32_t* out_dev);
+void launch_pairs_collect(hipStream_t s, const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces,
+                          uint32_t* cursor);
+void launch_pairs_insert(hipStream_t s, const PairTable& pt, const uint64_t* keys, const uint64_t* faces,
+                         uint64_t n, uint32_t* flags);
+void launch_pairs_clear(hipStream_t s, const PairTable& pt);
+void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3], int64_t a_begin,
+                  int64_t a_count, const int32_t* seeds_dev, const int32_t grid[3],
+                  const int64_t* ell_dev);
+
+// kernels_sweep.hip
+void launch_sweep(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);
+int sweep_default_tile_planes();
+
+}  // namespace ta

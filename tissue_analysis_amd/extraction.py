@@ -1,0 +1,178 @@
+"""Host side of the hot path: run the fused sweep through the C ABI and turn its exact integer
+accumulators into the float quantities the reference computes per label.
+
+Everything here is float64 numpy on *integers produced by the GPU*; there is no CPU path that
+scans voxels.  Formulas (SURVEY.md §8 "Semantics"):
+  barycentre  com  = sum1 / count                                   SIA:466-467
+  covariance  cov  = (sum2 - sum1.sum1^T / N) / max(3, N)           SIA:137-150, 1276-1278
+              evaluated on moments first shifted to the label's bounding-box origin in exact
+              integer arithmetic, which removes the cancellation of the raw global form
+  inertia     eigenpairs of cov, decreasing eigenvalue, vectors as rows          SIA:152-167
+  wall area   F0*v1*v2 + F1*v2*v0 + F2*v0*v1 (real) or F0+F1+F2 (voxels)  SIA:751-756, 947-956
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _capi
+
+PAIR_ORDER = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
+
+
+class Extraction(object):
+    """Exact integer result of one sweep (rows 0..max_label) + adjacency COO sorted by (lo, hi)."""
+
+    def __init__(self, shape, max_label, count, bbox, sum1, sum2, pair_lo, pair_hi, pair_faces,
+                 timing=None):
+        self.shape = tuple(int(s) for s in shape)
+        self.max_label = int(max_label)
+        self.count = np.asarray(count, dtype=np.uint64)
+        self.bbox = np.asarray(bbox, dtype=np.int32).reshape(-1, 6)
+        self.sum1 = np.asarray(sum1, dtype=np.uint64).reshape(-1, 3)
+        self.sum2 = np.asarray(sum2, dtype=np.uint64).reshape(-1, 6)
+        self.pair_lo = np.asarray(pair_lo, dtype=np.uint32)
+        self.pair_hi = np.asarray(pair_hi, dtype=np.uint32)
+        self.pair_faces = np.asarray(pair_faces, dtype=np.uint64).reshape(-1, 3)
+        self.timing = timing
+        self._csr = None
+
+    @classmethod
+    def from_arrays(cls, shape, arrays, timing=None):
+        """Build from a dict with the C-ABI array names (what tests / distributed merges hold)."""
+        return cls(shape, arrays["max_label"], arrays["count"], arrays["bbox"], arrays["sum1"],
+                   arrays["sum2"], arrays["pair_lo"], arrays["pair_hi"], arrays["pair_faces"], timing)
+
+    def as_arrays(self):
+        return dict(max_label=self.max_label, count=self.count, bbox=self.bbox, sum1=self.sum1,
+                    sum2=self.sum2, pair_lo=self.pair_lo, pair_hi=self.pair_hi,
+                    pair_faces=self.pair_faces)
+
+    # ------------------------------------------------------------------ labels / boxes
+    def present(self):
+        """Ascending ids of the labels that own at least one voxel."""
+        return np.nonzero(self.count)[0]
+
+    def has(self, label):
+        return 0 <= label <= self.max_label and self.count[label] > 0
+
+    def bbox_slices(self, label):
+        """(slice, slice, slice) like nd.find_objects, or None when the label is absent."""
+        if not self.has(label):
+            return None
+        b = self.bbox[label]
+        return tuple(slice(int(b[d]), int(b[3 + d])) for d in range(3))
+
+    # ------------------------------------------------------------------ moments
+    def volumes(self, labels):
+        return self.count[np.asarray(labels, dtype=np.int64)].astype(np.float64)
+
+    def barycenters(self, labels):
+        """float64 [n, 3], voxel units."""
+        idx = np.asarray(labels, dtype=np.int64)
+        n = self.count[idx].astype(np.float64)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            return self.sum1[idx].astype(np.float64) / n[:, None]
+
+    def covariances(self, labels):
+        """float64 [n, 3, 3] = sum (p - com)(p - com)^T / max(3, N)."""
+        idx = np.asarray(labels, dtype=np.int64)
+        N = self.count[idx].astype(np.int64)
+        o = np.where(self.bbox[idx, :3] < 0, 0, self.bbox[idx, :3]).astype(np.int64)   # bbox origin
+        s1 = self.sum1[idx].astype(np.int64)
+        s2 = self.sum2[idx].astype(np.int64)
+        s1s = s1 - N[:, None] * o                                                       # exact
+        cov = np.zeros((idx.size, 3, 3), dtype=np.float64)
+        Nf = N.astype(np.float64)
+        norm = np.maximum(3.0, Nf)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            for k, (d, e) in enumerate(PAIR_ORDER):
+                s2s = s2[:, k] - o[:, d] * s1[:, e] - o[:, e] * s1[:, d] + N * o[:, d] * o[:, e]
+                c = (s2s.astype(np.float64) - s1s[:, d].astype(np.float64) * s1s[:, e].astype(np.float64) / Nf) / norm
+                cov[:, d, e] = c
+                cov[:, e, d] = c
+        return cov
+
+    def inertia(self, labels):
+        """(vectors [n,3,3] rows = axes, values [n,3]) sorted by decreasing eigenvalue, like
+        eigen_values_vectors (SIA:152-167) which calls np.linalg.eig and re-orders."""
+        cov = self.covariances(labels)
+        if cov.shape[0] == 0:
+            return np.zeros((0, 3, 3)), np.zeros((0, 3))
+        cov = np.where(np.isfinite(cov), cov, 0.0)
+        val, vec = np.linalg.eig(cov)                    # LAPACK geev per matrix, same call as SIA:163
+        val = np.real(val)
+        vec = np.real(vec)
+        order = np.argsort(val, axis=1)[:, ::-1]
+        val = np.take_along_axis(val, order, axis=1)
+        vec = np.take_along_axis(vec, order[:, None, :], axis=2)      # columns re-ordered
+        return np.transpose(vec, (0, 2, 1)), val                      # rows = eigenvectors
+
+    # ------------------------------------------------------------------ adjacency
+    def _adjacency_csr(self):
+        if self._csr is None:
+            lo = self.pair_lo.astype(np.int64)
+            hi = self.pair_hi.astype(np.int64)
+            src = np.concatenate([lo, hi])
+            dst = np.concatenate([hi, lo])
+            pid = np.concatenate([np.arange(lo.size), np.arange(lo.size)])
+            order = np.lexsort((dst, src))
+            src, dst, pid = src[order], dst[order], pid[order]
+            nrows = max(self.max_label + 1, int(src.max()) + 1 if src.size else 0)
+            ptr = np.zeros(nrows + 1, dtype=np.int64)
+            np.add.at(ptr, src + 1, 1)
+            self._csr = (np.cumsum(ptr), dst, pid)
+        return self._csr
+
+    def neighbors_of(self, label):
+        """Ascending int list of the labels sharing at least one voxel face with `label`."""
+        ptr, dst, _ = self._adjacency_csr()
+        if label < 0 or label + 1 >= ptr.size:
+            return []
+        return [int(v) for v in dst[ptr[label]:ptr[label + 1]]]
+
+    def faces_between(self, label, others):
+        """uint64 [len(others), 3]: per-axis shared-face counts of (label, other); 0 when not adjacent."""
+        ptr, dst, pid = self._adjacency_csr()
+        out = np.zeros((len(others), 3), dtype=np.uint64)
+        if label < 0 or label + 1 >= ptr.size:
+            return out
+        row = dst[ptr[label]:ptr[label + 1]]
+        rid = pid[ptr[label]:ptr[label + 1]]
+        pos = np.searchsorted(row, np.asarray(others, dtype=np.int64))
+        for i, (p, o) in enumerate(zip(pos, others)):
+            if p < row.size and row[p] == o:
+                out[i] = self.pair_faces[rid[p]]
+        return out
+
+
+def full_mask():
+    return _capi.F_ALL
+
+
+def extract_volume(array, features=_capi.F_ALL, device=0, context=None, max_label=None,
+                   impl=None, tile_planes=None):
+    """Upload `array` (uint16/uint32, any dense layout) and run the fused sweep on the GPU."""
+    a = np.asarray(array)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    own = context is None
+    ctx = _capi.Context(device) if own else context
+    try:
+        if impl is not None:
+            ctx.set_option(_capi.OPT_IMPL, impl)
+        if tile_planes is not None:
+            ctx.set_option(_capi.OPT_TILE_PLANES, tile_planes)
+        ctx.set_volume(a)
+        if max_label is None:
+            max_label = ctx.max_label()
+        ctx.extract(features, max_label)
+        count, bbox, sum1, sum2 = ctx.labels()
+        if _capi.feature_mask(features) & _capi.F_ADJACENCY:
+            lo, hi, faces = ctx.adjacency()
+        else:
+            lo = hi = np.zeros(0, dtype=np.uint32)
+            faces = np.zeros((0, 3), dtype=np.uint64)
+        return Extraction(a.shape, max_label, count, bbox, sum1, sum2, lo, hi, faces, ctx.timing())
+    finally:
+        if own:
+            ctx.close()
