@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""bench.py -- full-feature extraction throughput of the fused HIP sweep on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one synthetic labelled volume that is already resident
+in HBM: accumulator init + fused sweep + adjacency collection (+ for N > 1 the per-label RCCL
+reduce and the adjacency merge).  N = 1 runs BASELINE.json's metric config (C4: 1024^3 uint32,
+~50k seeds, full feature set).  N > 1 is weak scaling with the same voxel count per GPU, Z-slab
+partitioned with a one-plane halo; N = 8 is exactly config C5 (2048^3, 100k seeds).
+
+Rank 0 prints ONE JSON line (contract in the task description), with two extra objects:
+  roofline     -- the sweep kernel's algorithmic bytes / its mean HIP-event duration vs 8 TB/s
+  cpu_baseline -- the per-label scipy restatement of the reference (oracle/, 1 core) timed on a
+                  bounded crop of the same volume on this node's host (rank 0, N = 1 only)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def weak_config(n_gpus):
+    """Volume for N ranks: 2^30 voxels per GPU; N=1 is C4, N=8 is C5."""
+    from tissue_analysis_amd import synth
+    table = {1: (1024, 1024, 1024), 2: (2048, 1024, 1024), 4: (2048, 2048, 1024), 8: (2048, 2048, 2048)}
+    if n_gpus in table:
+        dims = table[n_gpus]
+    else:
+        dims = (1024 * n_gpus, 1024, 1024)
+    if n_gpus == 1:
+        c = synth.CONFIGS["C4"]
+        return dict(name="C4", dims=c["dims"], dtype=c["dtype"], n_cells=c["n_cells"], seed=c["seed"])
+    if n_gpus == 8:
+        c = synth.CONFIGS["C5"]
+        return dict(name="C5", dims=c["dims"], dtype=c["dtype"], n_cells=c["n_cells"], seed=c["seed"])
+    n_cells = int(round(50000 * n_gpus ** (1.0 / 3.0)))
+    return dict(name="C4x%d" % n_gpus, dims=dims, dtype="uint32", n_cells=n_cells, seed=2)
+
+
+def cpu_baseline(vol_tensor, dims, dtype, edge=256):
+    """Time the oracle (reference algorithm restated, 1 core) on a centred crop of the volume."""
+    from oracle.sia_oracle import full_feature_set
+    from tissue_analysis_amd import synth
+    e = [min(edge, d) for d in dims]
+    lo = [(d - x) // 2 for d, x in zip(dims, e)]
+    crop = vol_tensor[lo[0]:lo[0] + e[0], lo[1]:lo[1] + e[1], lo[2]:lo[2] + e[2]].contiguous().cpu().numpy()
+    crop = crop.view(np.dtype(dtype))
+    t0 = time.perf_counter()
+    out = full_feature_set(crop, synth.PARITY_VOXELSIZE, background=1)
+    dt = time.perf_counter() - t0
+    return dict(value=round(crop.size / dt / 1e6, 3), unit="Mvoxels/s", cores=1, kind="port",
+                sample="centred %dx%dx%d crop of the bench volume, %d labels, full feature set "
+                       "(oracle/sia_oracle.py: per-label scipy.ndimage loops as in the reference), %.1f s"
+                       % (e[0], e[1], e[2], len(out["labels"]), dt),
+                host_cpus=os.cpu_count())
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default=None, help="override: C2/C3/C4/C5 on one GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tile-planes", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from tissue_analysis_amd import _capi, device as dev, distributed as tad, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    n = args.gpus
+    if world != n and not (n == 1 and world == 1):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (n, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if n > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+
+    if args.config:
+        c = synth.CONFIGS[args.config]
+        cfg = dict(name=args.config, dims=c["dims"], dtype=c["dtype"], n_cells=c["n_cells"], seed=c["seed"])
+        feats = _capi.feature_mask(c["features"])
+    else:
+        cfg = weak_config(n)
+        feats = _capi.F_ALL
+    dims, dtype = cfg["dims"], np.dtype(cfg["dtype"])
+
+    ctx = dev.torch_context(local_rank)
+    if args.tile_planes:
+        ctx.set_option(_capi.OPT_TILE_PLANES, args.tile_planes)
+    # Z-slab of this rank: planes [a_lo, a_hi) plus the plane below as low halo
+    a_lo, a_hi = tad.slab_range(dims[0], n, rank)
+    halo = 1 if a_lo > 0 else 0
+    vol, max_label = dev.synth_slab(ctx, dims, dtype, cfg["n_cells"], cfg["seed"], a_lo - halo, a_hi,
+                                    device=local_rank)
+    job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=a_lo, has_low_halo=bool(halo),
+                      max_label=max_label, features=feats, group=(dist.group.WORLD if n > 1 else None),
+                      device=local_rank)
+
+    def barrier():
+        if n > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        job.step()
+    barrier()
+    sweep_ms, adj_ms = [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        job.step()
+        if False:
+            pass
+    barrier()
+    dt = time.perf_counter() - t0
+    # per-kernel durations from the HIP events of the last steps (events live on the launch stream)
+    for _ in range(min(5, max(1, args.steps))):
+        job.step()
+        torch.cuda.synchronize()
+        t = ctx.timing()
+        sweep_ms.append(t["ms_sweep"])
+        adj_ms.append(t["ms_adjacency"])
+    bytes_read = ctx.timing()["bytes_read"]
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    if n > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+    nvox = float(dims[0]) * dims[1] * dims[2]
+    ms_per_step = dt / args.steps * 1e3
+    value = nvox * args.steps / dt / 1e6
+
+    if rank == 0:
+        labels_present = int((job.result_counts() > 0).sum())
+        sweep = float(np.mean(sweep_ms))
+        achieved = bytes_read / (sweep * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(cfg["name"])
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mvoxels/s full-feature extraction, 1024^3 vol/50k labels; % HBM roofline",
+            "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": n, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64",
+            "data": "synthetic jittered-grid Voronoi tissue in an ellipsoid (tissue_analysis_amd/synth.py), resident in HBM",
+            "config": {"workload": "%s: %dx%dx%d %s, %d seeds (%d labels present), features=0x%x, Z-slab x%d"
+                                   % (cfg["name"], dims[0], dims[1], dims[2], dtype.name, cfg["n_cells"],
+                                      labels_present, feats, n),
+                       "voxels_per_gpu": int(nvox / n), "label_dtype": dtype.name,
+                       "pct_hbm_roofline": round(100.0 * achieved / HBM_PEAK_GBS, 2)},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "sweep_kernel", "kernel_ms": round(sweep, 4),
+                         "adjacency_collect_ms": round(float(np.mean(adj_ms)), 4),
+                         "algorithmic_bytes_per_launch": int(bytes_read)},
+        }
+        if n == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(job.owned_view(), (a_hi - a_lo, dims[1], dims[2]), dtype)
+        print(json.dumps(out), flush=True)
+    if n > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

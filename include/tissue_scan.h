@@ -130,6 +130,10 @@ TA_API int ta_accumulators_device(ta_ctx* ctx, void** sums_dev, void** boxes_dev
  * keys uint64[n] = lo<<32|hi, faces uint64[n][3] (memory-axis order). */
 TA_API int ta_adjacency_device(ta_ctx* ctx, void** keys_dev, void** faces_dev, int64_t* npairs);
 
+/* Copy the unsorted unique pairs into caller-owned device buffers (e.g. torch tensors that an
+ * RCCL all-gather will send); capacity_pairs must be >= the current pair count. */
+TA_API int ta_adjacency_export(ta_ctx* ctx, void* keys_dst_dev, void* faces_dst_dev, int64_t capacity_pairs);
+
 /* Merge foreign pair lists (other ranks' ta_adjacency_device output, gathered by the host with
  * RCCL) into this context's adjacency: sums face counts of equal keys. */
 TA_API int ta_adjacency_merge(ta_ctx* ctx, const void* keys_dev, const void* faces_dev, int64_t npairs);

@@ -26,7 +26,7 @@ SYMBOLS = (
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_synchronize", "ta_volume_set",
     "ta_volume_set_device", "ta_volume_max_label", "ta_extract", "ta_get_labels",
     "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_bind_accumulators",
-    "ta_accumulators_device", "ta_adjacency_device", "ta_adjacency_merge", "ta_synth_voronoi",
+    "ta_accumulators_device", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge", "ta_synth_voronoi",
     "ta_device_malloc", "ta_device_free", "ta_memcpy_d2h", "ta_memcpy_h2d",
 )
 
@@ -73,6 +73,7 @@ def load():
         "ta_bind_accumulators": (ci, [vp, vp, vp, u32]),
         "ta_accumulators_device": (ci, [vp, P(vp), P(vp), P(u32)]),
         "ta_adjacency_device": (ci, [vp, P(vp), P(vp), P(i64)]),
+        "ta_adjacency_export": (ci, [vp, vp, vp, i64]),
         "ta_adjacency_merge": (ci, [vp, vp, vp, i64]),
         "ta_synth_voronoi": (ci, [vp, vp, ci, P(i64), i64, i64, vp, P(ctypes.c_int32), vp]),
         "ta_device_malloc": (ci, [vp, u64, P(vp)]),
@@ -229,6 +230,10 @@ class Context(object):
         k, f, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(0)
         _check(self._lib.ta_adjacency_device(self._h, ctypes.byref(k), ctypes.byref(f), ctypes.byref(n)))
         return k.value, f.value, n.value
+
+    def adjacency_export(self, keys_ptr, faces_ptr, capacity):
+        _check(self._lib.ta_adjacency_export(self._h, ctypes.c_void_p(int(keys_ptr) if keys_ptr else 0),
+                                             ctypes.c_void_p(int(faces_ptr) if faces_ptr else 0), int(capacity)))
 
     def adjacency_merge(self, keys_ptr, faces_ptr, npairs):
         _check(self._lib.ta_adjacency_merge(self._h, ctypes.c_void_p(int(keys_ptr) if keys_ptr else 0),

@@ -118,31 +118,59 @@ void launch_max_label(hipStream_t s, const void* vol, int itemsize, uint64_t nvo
 
 // ------------------------------------------------------------------------------------------
 // adjacency hash: collect (and self-clean), insert, clear
+// Each block owns a contiguous slot range: count its occupied slots, reserve output space with
+// ONE returning atomic per block (a single hot word sustains only ~88 atomics/us), then write.
 __global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64_t* out_keys,
-                                                            uint64_t* out_faces, uint32_t* cursor) {
+                                                            uint64_t* out_faces, uint32_t* cursor,
+                                                            uint32_t slots_per_block) {
+    __shared__ uint32_t wave_tot[4];
+    __shared__ uint32_t block_base;
     const uint64_t cap = (uint64_t)pt.mask + 1;
-    for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < cap;
-         h += (uint64_t)gridDim.x * blockDim.x) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint64_t lo = (uint64_t)blockIdx.x * slots_per_block;
+    const uint64_t hi = lo + slots_per_block < cap ? lo + slots_per_block : cap;
+    // pass 1: occupied slots per thread (coalesced 8-byte key reads)
+    uint32_t mine = 0;
+    for (uint64_t h = lo + tid; h < hi; h += 256) mine += pt.keys[h] != EMPTY_KEY;
+    // wave inclusive scan, then block offsets
+    uint32_t incl = mine;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off, 64);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    if (tid == 0) {
+        const uint32_t total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        block_base = total ? atomicAdd(cursor, total) : 0u;
+    }
+    __syncthreads();
+    uint32_t pos = block_base + incl - mine;
+    for (int i = 0; i < w; ++i) pos += wave_tot[i];
+    // pass 2: emit and self-clean (keys come back from L2)
+    for (uint64_t h = lo + tid; h < hi; h += 256) {
         const uint64_t k = pt.keys[h];
-        if (k != EMPTY_KEY) {
-            const uint32_t i = atomicAdd(cursor, 1u);        // wave-aggregated by the compiler
-            out_keys[i] = k;
-            out_faces[3ull * i + 0] = pt.faces[3 * h + 0];
-            out_faces[3ull * i + 1] = pt.faces[3 * h + 1];
-            out_faces[3ull * i + 2] = pt.faces[3 * h + 2];
-            pt.keys[h] = EMPTY_KEY;                          // leave the table clean for the next call
-            pt.faces[3 * h + 0] = 0; pt.faces[3 * h + 1] = 0; pt.faces[3 * h + 2] = 0;
-        }
+        if (k == EMPTY_KEY) continue;
+        out_keys[pos] = k;
+        out_faces[3ull * pos + 0] = pt.faces[3 * h + 0];
+        out_faces[3ull * pos + 1] = pt.faces[3 * h + 1];
+        out_faces[3ull * pos + 2] = pt.faces[3 * h + 2];
+        ++pos;
+        pt.keys[h] = EMPTY_KEY;                              // leave the table clean for the next call
+        pt.faces[3 * h + 0] = 0; pt.faces[3 * h + 1] = 0; pt.faces[3 * h + 2] = 0;
     }
 }
 
 void launch_pairs_collect(hipStream_t s, const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces,
                           uint32_t* cursor) {
-    uint64_t cap = (uint64_t)pt.mask + 1;
-    uint64_t blocks = (cap + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
+    const uint64_t cap = (uint64_t)pt.mask + 1;
+    uint64_t blocks = cap / 2048;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    const uint32_t per_block = (uint32_t)((cap + blocks - 1) / blocks);
     hipLaunchKernelGGL(pairs_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pt, out_keys,
-                       out_faces, cursor);
+                       out_faces, cursor, per_block);
 }
 
 __global__ void __launch_bounds__(256) pairs_insert_kernel(PairTable pt, const uint64_t* keys,

@@ -6,40 +6,53 @@
 // behind neighbors / cell_wall_area / wall_areas (SIA:538-660, 908-993).
 //
 // Work decomposition (memory axes: 0 slowest ... 2 fastest)
-//   workgroup = 4 waves stacked along axis 1; wave = RB rows x (64 lanes * VPL voxels) along
-//   axis 2; each lane keeps its RB x VPL voxels of the current plane in VGPRs (16-byte loads)
-//   and the workgroup walks `tile_planes` planes along axis 0 with the next plane prefetched.
-//   * axis-0 neighbours are the lane's own registers from the previous plane,
-//     axis-1 neighbours the row above in the same lane (+ one halo row per wave),
-//     axis-2 neighbours the previous voxel of the strip (+ one DPP wave-shift for voxel 0).
-//   * a label change along axis 0 closes a *column run*; a run (label, a0..a1, b, c) yields all
-//     ten moments in closed form, so moments cost one event per ~cell-diameter voxels, and that
-//     event is the same compare that detects the axis-0 face.
-//   * events are sparse per lane, so they are compacted (v_cmp mask -> mbcnt) into a small
-//     per-wave LDS ring and consumed 64 at a time with every lane busy.  The consumer updates
-//     two workgroup-shared LDS hash tables with LDS atomics: label -> {10 x u64 sums, bbox} and
-//     (lo,hi) -> 3 face counters.  The tables are flushed once per tile with global atomics
-//     (u64 add / i32 min), which is what makes the result independent of tiling and of order.
-//   * the kernel body is a resumable "event pump": producer phases (one per voxel slot and
-//     axis) are straight-line code with static register indices and there is exactly ONE
-//     consumer site, reached by a forward jump when the ring holds >= 64 records.
-//   * no MFMA: this is integer compare/reduce work bound by the HBM read of the volume.
+//   workgroup = 4 waves stacked along axis 1; wave tile = RB rows x (64 lanes * VPL voxels)
+//   along axis 2; the workgroup walks `tile_planes` planes along axis 0, next plane prefetched
+//   into registers with 16-byte loads while the current one is processed.
+//   Per plane ("step") a wave
+//     1. compares every voxel with its three predecessors entirely in registers (axis 0: the
+//        lane's registers from the previous plane; axis 1: the row above in the same lane + one
+//        halo row; axis 2: the previous voxel of the strip + one DPP wave shift) and packs the
+//        results into per-lane event bitmaps -- static register indices only;
+//     2. if no lane saw an event (interior of a cell, background) the step ends here: nothing
+//        is written, runs simply continue (this is ~60 % of a tissue-in-ellipsoid volume);
+//     3. otherwise stages the plane tile (+halo row/column) in LDS, prefix-scans the per-lane
+//        event counts with DPP and lets every lane append 4-byte POSITION CODES of its events to
+//        two per-wave LDS queues (faces / closed column runs);
+//     4. consumes the queues 64 records at a time with every lane busy: a consumer lane decodes
+//        its code, fetches the voxel and its neighbour from the LDS tile and updates two
+//        workgroup-shared LDS hash tables with LDS atomics:
+//           label -> {10 x u64 moment sums, bbox}      (one update per closed column run: a run
+//                                                      (label, a0..a1, b, c) gives all ten
+//                                                      moments in closed form)
+//           (lo,hi) -> 3 x u32 face counters.
+//   A wave tile that never saw an event is one label: it contributes a closed-form box.
+//   The tables are flushed once per workgroup tile with global atomics (u64 add / i32 min);
+//   integer sums and minima make the result independent of tiling, scheduling and order.
+//   No MFMA anywhere: integer compare/reduce work bound by the HBM read of the volume.
 #include "ta_kernels.h"
 
 namespace ta {
 
 constexpr int WAVES = 4;          // waves per workgroup, stacked along axis 1
-constexpr int QCAP = 128;         // per-wave ring capacity (records); a phase adds <= 64
+constexpr int QCAP = 256;         // per-wave queue capacity (position codes) = emission window
 constexpr int LSLOTS = 128;       // label table slots per workgroup
 constexpr int PSLOTS = 512;       // pair table slots per workgroup
 constexpr int LPROBE = 16;        // max probes before spilling to global atomics
 constexpr int PPROBE = 32;
 
-constexpr uint32_t META_RUN = 1u << 18, META_FACE = 1u << 19;
+template <int RB, int TC>
+struct __attribute__((aligned(16))) WaveLds {
+    static constexpr int RS = TC + 4;                 // row stride (dwords); dword 3 = left halo voxel
+    uint32_t tile[2][(RB + 1) * RS];                  // [plane parity][row 0 = halo row above | rows 1..RB]
+    uint32_t fq[QCAP];                                // face events: position codes
+    uint32_t rq[QCAP];                                // closed runs: position codes
+    uint8_t a0[RB * TC];                              // first plane (tile-local, < 256) of each column's open run
+};
 
-template <int NS>
+template <int NS, int RB, int TC>
 struct __attribute__((aligned(16))) SweepLds {
-    uint4 q[WAVES * QCAP];        // event rings: {a/old, b/new, run(a0|a1<<16), meta}
+    WaveLds<RB, TC> wave[WAVES];
     uint64_t lsum[LSLOTS * NS];
     uint64_t pkeys[PSLOTS];
     uint32_t lkeys[LSLOTS];
@@ -52,8 +65,15 @@ __device__ __forceinline__ uint32_t lane_shr1(uint32_t src, uint32_t lane0_value
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)src, 0x138, 0xf, 0xf, false);
 }
 
-__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+// inclusive add-scan over the 64 lanes of a wave with DPP row shifts + row broadcasts
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1,3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2,3
+    return x;
 }
 
 // ---- strip loads ---------------------------------------------------------------------------
@@ -76,31 +96,99 @@ __device__ __forceinline__ void load_strip(const T* row, bool row_ok, int64_t c,
     }
 }
 
-// ---- the wave body ---------------------------------------------------------------------------
-template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE>
-__device__ __forceinline__ void wave_sweep(const SweepArgs& A, SweepLds<MOM2 ? 10 : 4>& S,
-                                           const int lane, const int w, const int64_t c_tile0,
-                                           const int64_t b_tile0, const int64_t p_lo,
-                                           const int64_t p_hi) {
+// ---- workgroup-shared LDS tables -----------------------------------------------------------
+template <bool MOM2, typename LDS>
+__device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, uint32_t label,
+                                              const uint64_t (&sv)[NSUM], uint32_t mn0, uint32_t mx0,
+                                              uint32_t mn1, uint32_t mx1, uint32_t mn2, uint32_t mx2) {
     constexpr int NS = MOM2 ? 10 : 4;
+    uint32_t h = hash_u32(label) & (LSLOTS - 1);
+    int slot = -1;
+    for (int probe = 0; probe < LPROBE; ++probe) {
+        uint32_t k = S.lkeys[h];
+        if (k == INVALID_LABEL) {
+            k = atomicCAS(&S.lkeys[h], INVALID_LABEL, label);
+            if (k == INVALID_LABEL) k = label;
+        }
+        if (k == label) { slot = (int)h; break; }
+        h = (h + 1) & (LSLOTS - 1);
+    }
+    if (slot >= 0) {
+        unsigned long long* row = (unsigned long long*)&S.lsum[slot * NS];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) atomicAdd(row + k, (unsigned long long)sv[k]);
+        uint32_t* box = &S.lbox[slot * 6];
+        atomicMin(box + 0, mn0); atomicMax(box + 3, mx0);
+        atomicMin(box + 1, mn1); atomicMax(box + 4, mx1);
+        atomicMin(box + 2, mn2); atomicMax(box + 5, mx2);
+    } else {                                       // table full: straight to the global rows
+        atomicOr(&A.flags[FLAG_LDS_LABEL_SPILL], 1u);
+        if (label > A.max_label) { atomicOr(&A.flags[FLAG_RANGE], 1u); return; }
+        unsigned long long* row = (unsigned long long*)&A.sums[(uint64_t)label * NSUM];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) atomicAdd(row + k, (unsigned long long)sv[k]);
+        int32_t* box = &A.boxes[(uint64_t)label * NBOX];
+        atomicMin(box + 0, (int32_t)mn0); atomicMin(box + 3, -(int32_t)mx0);
+        atomicMin(box + 1, (int32_t)mn1); atomicMin(box + 4, -(int32_t)mx1);
+        atomicMin(box + 2, (int32_t)mn2); atomicMin(box + 5, -(int32_t)mx2);
+    }
+}
+
+template <typename LDS>
+__device__ __forceinline__ void lds_pair_add(const SweepArgs& A, LDS& S, uint32_t a, uint32_t b,
+                                             uint32_t axis) {
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    const uint64_t key = ((uint64_t)lo << 32) | hi;
+    uint32_t h = hash_pair(lo, hi) & (PSLOTS - 1);
+    int slot = -1;
+    for (int probe = 0; probe < PPROBE; ++probe) {
+        uint64_t k = S.pkeys[h];
+        if (k == EMPTY_KEY) {
+            k = atomicCAS((unsigned long long*)&S.pkeys[h], (unsigned long long)EMPTY_KEY,
+                          (unsigned long long)key);
+            if (k == EMPTY_KEY) k = key;
+        }
+        if (k == key) { slot = (int)h; break; }
+        h = (h + 1) & (PSLOTS - 1);
+    }
+    if (slot >= 0) {
+        atomicAdd(&S.pcnt[slot * 3 + axis], 1u);
+    } else {
+        atomicOr(&A.flags[FLAG_LDS_PAIR_SPILL], 1u);
+        pair_add_global(A.pairs, lo, hi, axis == 0, axis == 1, axis == 2, A.flags);
+    }
+}
+
+// sum_{x=x0}^{x0+n-1} x  and  x^2  (exact, u64)
+__device__ __forceinline__ uint64_t range_sum1(uint64_t x0, uint64_t n) { return n * x0 + n * (n - 1) / 2; }
+__device__ __forceinline__ uint64_t range_sum2(uint64_t x0, uint64_t n) {
+    return n * x0 * x0 + x0 * n * (n - 1) + (n - 1) * n * (2 * n - 1) / 6;
+}
+
+// ---- the wave body ---------------------------------------------------------------------------
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, typename LDS>
+__device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const int lane, const int w,
+                                           const int64_t c_tile0, const int64_t b_tile0,
+                                           const int64_t p_lo, const int64_t p_hi) {
+    constexpr int TC = 64 * VPL;
+    constexpr int RS = TC + 4;
     constexpr int NSLOT = RB * VPL;
-    // phases: [0, 2*NSLOT) face phases (axis 1 then axis 2 per slot), [PA, PA+NSLOT) axis-0 phases,
-    // P_ADV plane advance, [PE, PE+NSLOT) end-of-tile run flush, P_DONE.
-    constexpr int PA = 2 * NSLOT, P_ADV = PA + NSLOT, PE = P_ADV + 1, P_DONE = PE + NSLOT;
+    static_assert(NSLOT == 16, "event bitmaps assume 16 voxels per lane per plane");
+    constexpr int JSH = VPL == 4 ? 2 : 3;                // log2(VPL)
+    auto& W = S.wave[w];
 
     const T* vol = reinterpret_cast<const T*>(A.vol);
     const int64_t n1 = A.n1, n2 = A.n2, plane = n1 * n2;
     const int64_t b_wave0 = b_tile0 + (int64_t)w * RB;
     const int64_t c0 = c_tile0 + (int64_t)lane * VPL;
-    const bool has_up = b_wave0 > 0;
-    const bool has_left = c_tile0 > 0;
+    const bool has_up = ADJ && b_wave0 > 0;
+    const bool has_left = ADJ && c_tile0 > 0;
     const bool has_prev = p_lo > 0;
-    const int qbase = w * QCAP;
 
-    uint32_t cur[RB][VPL], nxt[RB][VPL], runlab[RB][VPL], a0s[RB][VPL];
+    uint32_t cur[RB][VPL], nxt[RB][VPL], prev[RB][VPL];
     uint32_t up[VPL], nxt_up[VPL], left[RB], nxt_left[RB];
 
-    auto load_plane = [&](int64_t p, uint32_t (&d)[RB][VPL], uint32_t (&dup)[VPL], uint32_t (&dl)[RB]) {
+    auto load_rows = [&](int64_t p, uint32_t (&d)[RB][VPL]) {
         const T* pbase = vol + p * plane;
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
@@ -108,244 +196,256 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, SweepLds<MOM2 ? 1
             const bool row_ok = b < n1;
             const T* row = pbase + (EDGE ? (row_ok ? b : 0) : b) * n2;
             load_strip<T, VPL, EDGE>(row, row_ok, c0, n2, d[r]);
-            if (ADJ) {
+        }
+    };
+    auto load_halo = [&](int64_t p, uint32_t (&dup)[VPL], uint32_t (&dl)[RB]) {
+        const T* pbase = vol + p * plane;
+        if (has_left) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r) {
+                const int64_t b = b_wave0 + r;
                 dl[r] = INVALID_LABEL;
-                if (has_left && lane == 0 && row_ok) dl[r] = (uint32_t)row[c_tile0 - 1];
+                if (lane == 0 && b < n1) dl[r] = (uint32_t)pbase[b * n2 + c_tile0 - 1];
             }
         }
-        if (ADJ) {
-            if (has_up) {
-                const bool row_ok = (b_wave0 - 1) < n1;
-                const T* row = pbase + (EDGE ? (row_ok ? (b_wave0 - 1) : 0) : (b_wave0 - 1)) * n2;
-                load_strip<T, VPL, EDGE>(row, row_ok, c0, n2, dup);
-            } else {
+        if (has_up) {
+            const bool row_ok = (b_wave0 - 1) < n1;
+            const T* row = pbase + (EDGE ? (row_ok ? (b_wave0 - 1) : 0) : (b_wave0 - 1)) * n2;
+            load_strip<T, VPL, EDGE>(row, row_ok, c0, n2, dup);
+        }
+    };
+    auto store_rows = [&](int buf, const uint32_t (&d)[RB][VPL]) {
+        uint32_t* tb = &W.tile[buf][0];
 #pragma unroll
-                for (int j = 0; j < VPL; ++j) dup[j] = INVALID_LABEL;
+        for (int r = 0; r < RB; ++r) {
+#pragma unroll
+            for (int q = 0; q < VPL / 4; ++q)
+                *reinterpret_cast<uint4*>(&tb[(r + 1) * RS + 4 + lane * VPL + 4 * q]) =
+                    make_uint4(d[r][4 * q + 0], d[r][4 * q + 1], d[r][4 * q + 2], d[r][4 * q + 3]);
+        }
+    };
+
+    // ---- consumers (64 records per pass, every lane busy) ------------------------------------
+    // faces: code = c_loc | r<<10 | axis<<13 ; voxel in tile[buf], predecessor by address offset
+    auto consume_faces = [&](int count, int buf) {
+        for (int base = 0; base < count; base += 64) {
+            const int i = base + lane;
+            if (i < count) {
+                const uint32_t code = W.fq[i];
+                const uint32_t cl = code & 1023u, r = (code >> 10) & 7u, axis = code >> 13;
+                const int off = (int)((r + 1) * RS + 4 + cl);
+                const uint32_t v = W.tile[buf][off];
+                uint32_t pv;
+                if (axis == 0) pv = W.tile[buf ^ 1][off];
+                else pv = W.tile[buf][axis == 1 ? off - RS : off - 1];
+                if (v != INVALID_LABEL && pv != INVALID_LABEL && v != pv) lds_pair_add(A, S, pv, v, axis);
+            }
+        }
+    };
+    // runs: the column (r, c_loc) closes the run [a0, a1_loc] of the label stored in tile[lbuf]
+    auto consume_runs = [&](int count, int lbuf, uint32_t a1_loc, bool reopen) {
+        for (int base = 0; base < count; base += 64) {
+            const int i = base + lane;
+            if (i < count) {
+                const uint32_t code = W.rq[i];
+                const uint32_t cl = code & 1023u, r = (code >> 10) & 7u;
+                const uint32_t label = W.tile[lbuf][(r + 1) * RS + 4 + cl];
+                const uint32_t a0l = W.a0[r * TC + cl];
+                if (reopen) W.a0[r * TC + cl] = (uint8_t)(a1_loc + 1u);
+                if (label != INVALID_LABEL) {
+                    const uint64_t gc = (uint64_t)(c_tile0 + (int64_t)cl);
+                    const uint64_t gb = (uint64_t)(b_wave0 + (int64_t)r);
+                    const uint64_t ga0 = (uint64_t)(A.a_origin + (p_lo + a0l - A.first_owned));
+                    const uint32_t n = a1_loc - a0l + 1u;
+                    uint64_t sv[NSUM];
+                    run_moments<MOM2>(ga0, n, gb, gc, sv);
+                    lds_label_add<MOM2>(A, S, label, sv, (uint32_t)ga0, (uint32_t)(ga0 + n - 1),
+                                        (uint32_t)gb, (uint32_t)gb, (uint32_t)gc, (uint32_t)gc);
+                }
             }
         }
     };
 
-    // ---- prologue: plane before the tile (faces only), first plane, prefetch of the second
+    // ---- prologue ------------------------------------------------------------------------------
     if (has_prev) {
-        uint32_t tmp_up[VPL], tmp_left[RB];
-        // only the voxels themselves matter for the previous plane
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-            const int64_t b = b_wave0 + r;
-            const bool row_ok = b < n1;
-            const T* row = vol + (p_lo - 1) * plane + (EDGE ? (row_ok ? b : 0) : b) * n2;
-            load_strip<T, VPL, EDGE>(row, row_ok, c0, n2, runlab[r]);
-        }
-        (void)tmp_up; (void)tmp_left;
+        load_rows(p_lo - 1, prev);
     } else {
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) runlab[r][j] = INVALID_LABEL;
+            for (int j = 0; j < VPL; ++j) prev[r][j] = INVALID_LABEL;
     }
-    load_plane(p_lo, cur, up, left);
-    if (p_lo + 1 < p_hi) load_plane(p_lo + 1, nxt, nxt_up, nxt_left);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) { up[j] = INVALID_LABEL; nxt_up[j] = INVALID_LABEL; }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) { left[r] = INVALID_LABEL; nxt_left[r] = INVALID_LABEL; }
+    load_rows(p_lo, cur);
+    load_halo(p_lo, up, left);
+    if (p_lo + 1 < p_hi) { load_rows(p_lo + 1, nxt); load_halo(p_lo + 1, nxt_up, nxt_left); }
 #pragma unroll
     for (int r = 0; r < RB; ++r)
 #pragma unroll
-        for (int j = 0; j < VPL; ++j) a0s[r][j] = 0;
+        for (int q = 0; q < VPL / 4; ++q)
+            *reinterpret_cast<uint32_t*>(&W.a0[r * TC + lane * VPL + 4 * q]) = 0u;
 
-    int64_t p = p_lo;           // plane being processed
-    bool first = true;          // processing the first owned plane of the tile
-    bool finished = false;
-    int phase = ADJ ? 0 : PA;
-    int head = 0, tail = 0;     // wave-uniform ring cursors (free-running)
+    int buf = 0;                 // LDS plane buffer that receives the current plane
+    bool prev_in_lds = false;    // tile[buf ^ 1] holds `prev`
+    bool any_event = false;      // this wave tile has seen at least one event
+    const uint32_t first_label = __builtin_amdgcn_readfirstlane(cur[0][0]);
 
-#define TA_EMIT(EV, RA, RBV, RRUN, RMETA)                                                   \
-    do {                                                                                    \
-        const uint64_t m_ = __builtin_amdgcn_ballot_w64(EV);                                \
-        if (m_) {                                                                           \
-            const uint32_t i_ = mbcnt64(m_);                                                \
-            if (EV) S.q[qbase + ((tail + (int)i_) & (QCAP - 1))] = make_uint4((RA), (RBV), (RRUN), (RMETA)); \
-            tail += __popcll(m_);                                                           \
-        }                                                                                   \
-    } while (0)
+    for (int64_t p = p_lo; p < p_hi; ++p) {
+        const bool first = p == p_lo;
+        const uint32_t ploc = (uint32_t)(p - p_lo);
 
-    for (;;) {
-        // ------------------------------------------------------------ producer: face phases
-        if (ADJ && phase < PA) {
+        // ---- 1. event bitmaps, registers only
+        uint32_t e0 = 0, e1 = 0;         // e0: axis-1 bits [0,16) | axis-2 bits [16,32) ; e1: axis-0 bits
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const int s = r * VPL + j;
+                const uint32_t v = cur[r][j];
+                if (ADJ) {
+                    if (r > 0) e0 |= (uint32_t)(v != cur[r > 0 ? r - 1 : 0][j]) << s;
+                    else if (has_up) e0 |= (uint32_t)(v != up[j]) << s;
+                    uint32_t pc;
+                    if (j == 0) pc = lane_shr1(cur[r][VPL - 1], has_left ? left[r] : cur[r][0]);
+                    else pc = cur[r][j > 0 ? j - 1 : 0];
+                    e0 |= (uint32_t)(v != pc) << (16 + s);
+                }
+                e1 |= (uint32_t)(v != prev[r][j]) << s;
+            }
+        }
+        if (first && !(ADJ && has_prev)) e1 = 0;     // nothing before the tile: no face, no run
+
+        // ---- 2. nobody saw anything: the step is over
+        const uint32_t nev = (uint32_t)__popc(e0) + (uint32_t)__popc(e1);
+        const uint32_t nrun = first ? 0u : (uint32_t)__popc(e1);
+        if (__builtin_amdgcn_ballot_w64(nev != 0) != 0) {
+            any_event = true;
+            // ---- 3. stage the plane in LDS, scan the counts, emit position codes
+            store_rows(buf, cur);
+            if (ADJ) {
+                if (has_up) {
+#pragma unroll
+                    for (int q = 0; q < VPL / 4; ++q)
+                        *reinterpret_cast<uint4*>(&W.tile[buf][4 + lane * VPL + 4 * q]) =
+                            make_uint4(up[4 * q + 0], up[4 * q + 1], up[4 * q + 2], up[4 * q + 3]);
+                }
+                if (has_left && lane == 0) {
+#pragma unroll
+                    for (int r = 0; r < RB; ++r) W.tile[buf][(r + 1) * RS + 3] = left[r];
+                }
+            }
+            if (!prev_in_lds) store_rows(buf ^ 1, prev);
+
+            const uint32_t packed = nev | (nrun << 16);
+            const uint32_t incl = wave_scan_add(packed);
+            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const int tot_ev = (int)(total & 0xffffu);
+            int fidx = (int)((incl - packed) & 0xffffu);     // index of this lane's next event
+            int ridx = (int)((incl - packed) >> 16);         // index of this lane's next run record
+            int rbase = 0;                                   // run records emitted in earlier windows
+            for (int win = 0; win < tot_ev; win += QCAP) {
+                int nrun_win = 0;
+                for (;;) {
+                    const bool can = ((e0 | e1) != 0u) && (fidx < win + QCAP);
+                    const uint64_t m = __builtin_amdgcn_ballot_w64(can);
+                    if (m == 0) break;
+                    bool isrun = false;
+                    if (can) {
+                        const bool isa = e0 == 0u;
+                        const uint32_t bits = isa ? e1 : e0;
+                        const uint32_t k = (uint32_t)__builtin_ctz(bits);
+                        if (isa) e1 = bits & (bits - 1u); else e0 = bits & (bits - 1u);
+                        const uint32_t s = k & 15u;
+                        const uint32_t axis = isa ? 0u : 1u + (k >> 4);
+                        const uint32_t code = ((uint32_t)lane * VPL + (s & (VPL - 1))) | ((s >> JSH) << 10);
+                        if (ADJ) W.fq[fidx - win] = code | (axis << 13);
+                        ++fidx;
+                        isrun = isa && !first;
+                        if (isrun) { W.rq[ridx - rbase] = code; ++ridx; }
+                    }
+                    nrun_win += __popcll(__builtin_amdgcn_ballot_w64(isrun));
+                }
+                __builtin_amdgcn_wave_barrier();
+                // ---- 4. dense consumers
+                const int nface_win = tot_ev - win < QCAP ? tot_ev - win : QCAP;
+                if (ADJ) consume_faces(nface_win, buf);
+                if (nrun_win) consume_runs(nrun_win, buf ^ 1, ploc - 1u, true);
+                rbase += nrun_win;
+                __builtin_amdgcn_wave_barrier();
+            }
+            prev_in_lds = true;
+            buf ^= 1;
+        } else {
+            prev_in_lds = false;
+        }
+
+        // ---- advance: current plane becomes the previous one, prefetched plane becomes current
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) prev[r][j] = cur[r][j];
+        if (p + 1 < p_hi) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
 #pragma unroll
-                for (int j = 0; j < VPL; ++j) {
-                    const int s = r * VPL + j;
-                    if (phase == 2 * s) {                      // axis 1: voxel vs the row above
-                        const uint32_t v = cur[r][j];
-                        const uint32_t pv = (r == 0) ? up[j] : cur[r == 0 ? 0 : r - 1][j];
-                        bool ev = v != pv;
-                        if (EDGE || r == 0) ev = ev && (v != INVALID_LABEL) && (pv != INVALID_LABEL);
-                        TA_EMIT(ev, pv, v, 0u, (1u << 16) | META_FACE);
-                        phase = 2 * s + 1;
-                        if (tail - head >= 64) goto consume;
-                    }
-                    if (phase == 2 * s + 1) {                  // axis 2: voxel vs its predecessor
-                        const uint32_t v = cur[r][j];
-                        uint32_t pv;
-                        if (j == 0) pv = lane_shr1(cur[r][VPL - 1], left[r]);
-                        else pv = cur[r][j == 0 ? 0 : j - 1];
-                        bool ev = v != pv;
-                        if (EDGE || j == 0) ev = ev && (v != INVALID_LABEL) && (pv != INVALID_LABEL);
-                        TA_EMIT(ev, pv, v, 0u, (2u << 16) | META_FACE);
-                        phase = 2 * s + 2;
-                        if (tail - head >= 64) goto consume;
-                    }
-                }
+                for (int j = 0; j < VPL; ++j) cur[r][j] = nxt[r][j];
+                left[r] = nxt_left[r];
             }
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) up[j] = nxt_up[j];
+            if (p + 2 < p_hi) { load_rows(p + 2, nxt); load_halo(p + 2, nxt_up, nxt_left); }
         }
-        // ------------------------------------------------------------ producer: axis-0 phases
-        if (phase >= PA && phase < P_ADV) {
-            const uint32_t ploc = (uint32_t)(p - p_lo);
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) {
-                    const int s = r * VPL + j;
-                    if (phase == PA + s) {
-                        const uint32_t v = cur[r][j], old = runlab[r][j];
-                        const uint32_t pos = (uint32_t)(lane * VPL + j) | ((uint32_t)(w * RB + r) << 10);
-                        bool ev = v != old;
-                        if (first) {
-                            // `old` is the plane before the tile: a face, never a run of this tile
-                            if (ADJ && has_prev) {
-                                ev = ev && (v != INVALID_LABEL) && (old != INVALID_LABEL);
-                                TA_EMIT(ev, old, v, 0u, META_FACE);
-                            }
-                        } else {
-                            TA_EMIT(ev, old, v, a0s[r][j] | ((ploc - 1u) << 16),
-                                    pos | META_RUN | (ADJ ? META_FACE : 0u));
-                            a0s[r][j] = ev ? ploc : a0s[r][j];
-                        }
-                        runlab[r][j] = v;
-                        phase = PA + s + 1;
-                        if (tail - head >= 64) goto consume;
-                    }
-                }
-            }
-        }
-        // ------------------------------------------------------------ plane advance
-        if (phase == P_ADV) {
-            first = false;
-            ++p;
-            if (p < p_hi) {
-#pragma unroll
-                for (int r = 0; r < RB; ++r) {
-#pragma unroll
-                    for (int j = 0; j < VPL; ++j) cur[r][j] = nxt[r][j];
-                    left[r] = nxt_left[r];
-                }
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) up[j] = nxt_up[j];
-                if (p + 1 < p_hi) load_plane(p + 1, nxt, nxt_up, nxt_left);
-                phase = ADJ ? 0 : PA;
-                continue;
-            }
-            phase = PE;
-        }
-        // ------------------------------------------------------------ end of tile: close every run
-        if (phase >= PE && phase < P_DONE) {
-            const uint32_t last = (uint32_t)(p_hi - 1 - p_lo);
-#pragma unroll
-            for (int r = 0; r < RB; ++r) {
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) {
-                    const int s = r * VPL + j;
-                    if (phase == PE + s) {
-                        const uint32_t pos = (uint32_t)(lane * VPL + j) | ((uint32_t)(w * RB + r) << 10);
-                        const bool ev = runlab[r][j] != INVALID_LABEL;
-                        TA_EMIT(ev, runlab[r][j], 0u, a0s[r][j] | (last << 16), pos | META_RUN);
-                        phase = PE + s + 1;
-                        if (tail - head >= 64) goto consume;
-                    }
-                }
-            }
-        }
-        if (phase == P_DONE) finished = true;
-
-    consume:
-        // ------------------------------------------------------------ the single consumer site
-        for (;;) {
-            const int cnt = tail - head;
-            if (cnt < 64 && !(finished && cnt > 0)) break;
-            __builtin_amdgcn_wave_barrier();
-            const uint4 rec = S.q[qbase + ((head + lane) & (QCAP - 1))];
-            const bool act = lane < cnt;
-            head += cnt < 64 ? cnt : 64;
-            if (act) {
-                const uint32_t meta = rec.w;
-                if (ADJ && (meta & META_FACE)) {
-                    const uint32_t lo = rec.x < rec.y ? rec.x : rec.y, hi = rec.x < rec.y ? rec.y : rec.x;
-                    const uint32_t axis = (meta >> 16) & 3u;
-                    const uint64_t key = ((uint64_t)lo << 32) | hi;
-                    uint32_t h = hash_pair(lo, hi) & (PSLOTS - 1);
-                    int slot = -1;
-                    for (int probe = 0; probe < PPROBE; ++probe) {
-                        uint64_t k = S.pkeys[h];
-                        if (k == EMPTY_KEY) {
-                            k = atomicCAS((unsigned long long*)&S.pkeys[h], (unsigned long long)EMPTY_KEY,
-                                          (unsigned long long)key);
-                            if (k == EMPTY_KEY) k = key;
-                        }
-                        if (k == key) { slot = (int)h; break; }
-                        h = (h + 1) & (PSLOTS - 1);
-                    }
-                    if (slot >= 0) {
-                        atomicAdd(&S.pcnt[slot * 3 + axis], 1u);
-                    } else {
-                        pair_add_global(A.pairs, lo, hi, axis == 0, axis == 1, axis == 2, A.flags);
-                        atomicOr(&A.flags[FLAG_LDS_PAIR_SPILL], 1u);
-                    }
-                }
-                if (meta & META_RUN) {
-                    const uint32_t label = rec.x;
-                    const uint32_t a0l = rec.z & 0xffffu, a1l = rec.z >> 16;
-                    const uint64_t gc = (uint64_t)(c_tile0 + (int64_t)(meta & 1023u));
-                    const uint64_t gb = (uint64_t)(b_tile0 + (int64_t)((meta >> 10) & 63u));
-                    const uint64_t ga0 = (uint64_t)(A.a_origin + (p_lo + a0l - A.first_owned));
-                    const uint32_t n = a1l - a0l + 1u;
-                    uint32_t h = hash_u32(label) & (LSLOTS - 1);
-                    int slot = -1;
-                    for (int probe = 0; probe < LPROBE; ++probe) {
-                        uint32_t k = S.lkeys[h];
-                        if (k == INVALID_LABEL) {
-                            k = atomicCAS(&S.lkeys[h], INVALID_LABEL, label);
-                            if (k == INVALID_LABEL) k = label;
-                        }
-                        if (k == label) { slot = (int)h; break; }
-                        h = (h + 1) & (LSLOTS - 1);
-                    }
-                    if (slot >= 0) {
-                        uint64_t sv[NSUM];
-                        run_moments<MOM2>(ga0, n, gb, gc, sv);
-                        unsigned long long* row = (unsigned long long*)&S.lsum[slot * NS];
-#pragma unroll
-                        for (int k = 0; k < NS; ++k) atomicAdd(row + k, (unsigned long long)sv[k]);
-                        uint32_t* box = &S.lbox[slot * 6];
-                        atomicMin(box + 0, (uint32_t)ga0); atomicMax(box + 3, (uint32_t)(ga0 + n - 1));
-                        atomicMin(box + 1, (uint32_t)gb);  atomicMax(box + 4, (uint32_t)gb);
-                        atomicMin(box + 2, (uint32_t)gc);  atomicMax(box + 5, (uint32_t)gc);
-                    } else {
-                        run_add_global<MOM2>(A, label, ga0, n, gb, gc);
-                        atomicOr(&A.flags[FLAG_LDS_LABEL_SPILL], 1u);
-                    }
-                }
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (finished) break;
     }
-#undef TA_EMIT
+
+    // ---- end of tile: close every open run --------------------------------------------------
+    const uint32_t last = (uint32_t)(p_hi - 1 - p_lo);
+    if (ADJ && !any_event) {
+        // no event at all (needs the in-plane compares of ADJ): the whole wave tile is one label (or lies outside the volume): closed-form box
+        if (lane == 0 && first_label != INVALID_LABEL) {
+            const uint64_t na = last + 1u, nb = RB, nc = TC;
+            const uint64_t ga = (uint64_t)(A.a_origin + (p_lo - A.first_owned)), gb = (uint64_t)b_wave0,
+                           gc = (uint64_t)c_tile0;
+            const uint64_t sa = range_sum1(ga, na), sb = range_sum1(gb, nb), sc = range_sum1(gc, nc);
+            uint64_t sv[NSUM];
+            sv[0] = na * nb * nc; sv[1] = sa * nb * nc; sv[2] = sb * na * nc; sv[3] = sc * na * nb;
+            if (MOM2) {
+                sv[4] = range_sum2(ga, na) * nb * nc; sv[5] = sa * sb * nc; sv[6] = sa * sc * nb;
+                sv[7] = range_sum2(gb, nb) * na * nc; sv[8] = sb * sc * na; sv[9] = range_sum2(gc, nc) * na * nb;
+            } else {
+                sv[4] = sv[5] = sv[6] = sv[7] = sv[8] = sv[9] = 0;
+            }
+            lds_label_add<MOM2>(A, S, first_label, sv, (uint32_t)ga, (uint32_t)(ga + na - 1), (uint32_t)gb,
+                                (uint32_t)(gb + nb - 1), (uint32_t)gc, (uint32_t)(gc + nc - 1));
+        }
+    } else {
+        // `prev` holds the last plane; make sure LDS does too, then run every column through
+        // the run consumer (QCAP codes per window)
+        const int lbuf = buf ^ 1;
+        if (!prev_in_lds) store_rows(lbuf, prev);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+#pragma unroll
+            for (int q = 0; q < VPL / 4; ++q) {
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    W.rq[j * 64 + lane] = ((uint32_t)lane * VPL + 4 * q + j) | ((uint32_t)r << 10);
+                __builtin_amdgcn_wave_barrier();
+                consume_runs(QCAP, lbuf, last, false);
+            }
+        }
+    }
 }
 
 template <typename T, int VPL, int RB, bool ADJ, bool MOM2>
 __global__ void __launch_bounds__(WAVES * 64) sweep_kernel(SweepArgs A) {
     constexpr int NS = MOM2 ? 10 : 4;
     constexpr int TC = 64 * VPL, TB = WAVES * RB;
-    __shared__ SweepLds<NS> S;
+    using LDS = SweepLds<NS, RB, TC>;
+    __shared__ LDS S;
 
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int i = tid; i < LSLOTS; i += WAVES * 64) {

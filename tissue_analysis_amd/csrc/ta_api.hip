@@ -142,7 +142,7 @@ int run_extract(ta_ctx* c) {
     a.a_origin = c->a_origin;
     a.first_owned = c->first_owned;
     a.tile_planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes();
-    if (a.tile_planes > 4096) a.tile_planes = 4096;
+    if (a.tile_planes > 255) a.tile_planes = 255;   // run starts are kept as u8 in LDS
     a.vec_ok = (((uintptr_t)c->vol & 15) == 0) && ((a.n2 * c->itemsize) % 16 == 0);
     a.max_label = c->max_label;
     a.sums = c->sums;
@@ -270,7 +270,7 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
             if (value != 0 && value != 1) return fail(TA_EINVAL, "TA_OPT_IMPL must be 0 or 1");
             c->impl = (int)value; return TA_OK;
         case TA_OPT_TILE_PLANES:
-            if (value < 0 || value > 4096) return fail(TA_EINVAL, "TA_OPT_TILE_PLANES must be in [0,4096]");
+            if (value < 0 || value > 255) return fail(TA_EINVAL, "TA_OPT_TILE_PLANES must be in [0,255]");
             c->tile_planes = (int)value; return TA_OK;
         case TA_OPT_PAIR_SLOTS:
             if (value != 0 && (value < 4 || value > 30)) return fail(TA_EINVAL, "TA_OPT_PAIR_SLOTS must be 0 or in [4,30]");
@@ -519,6 +519,20 @@ TA_API int ta_adjacency_device(ta_ctx* c, void** keys_dev, void** faces_dev, int
     if (keys_dev) *keys_dev = c->out_keys.p;
     if (faces_dev) *faces_dev = c->out_faces.p;
     if (npairs) *npairs = c->npairs;
+    return TA_OK;
+}
+
+TA_API int ta_adjacency_export(ta_ctx* c, void* keys_dst_dev, void* faces_dst_dev, int64_t capacity_pairs) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    if ((rc = finish_extract(c)) != TA_OK) return rc;
+    if (capacity_pairs < c->npairs) return fail(TA_EINVAL, "export buffers hold %lld pairs, %lld needed", (long long)capacity_pairs, (long long)c->npairs);
+    if (c->npairs > 0) {
+        if (!keys_dst_dev || !faces_dst_dev) return fail(TA_EINVAL, "NULL export buffer");
+        TA_HIP(hipMemcpyAsync(keys_dst_dev, c->out_keys.p, (uint64_t)c->npairs * 8, hipMemcpyDeviceToDevice, c->stream));
+        TA_HIP(hipMemcpyAsync(faces_dst_dev, c->out_faces.p, (uint64_t)c->npairs * 24, hipMemcpyDeviceToDevice, c->stream));
+    }
     return TA_OK;
 }
 
