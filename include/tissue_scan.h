@@ -116,6 +116,11 @@ TA_API int ta_adjacency_get(ta_ctx* ctx, uint32_t* lo, uint32_t* hi, uint64_t* f
 TA_API int ta_timing(ta_ctx* ctx, double* ms_sweep, double* ms_adjacency, double* ms_total,
               uint64_t* bytes_read);
 
+/* Diagnostics of the last ta_extract: out[0] = label-range flag, out[1] = adjacency-table overflow
+ * flag, out[2] = run records that missed the workgroup LDS label table (went to global atomics),
+ * out[3] = face records that missed the LDS pair table, out[4..7] reserved. */
+TA_API int ta_debug_counters(ta_ctx* ctx, uint32_t out[8]);
+
 /* ---- device-side views for the multi-GPU reduce (RCCL runs on these in place) -------------
  * sums  : uint64 [L+1][10] = count, s0, s1, s2, s00, s01, s02, s11, s12, s22   (reduce: SUM)
  * boxes : int32  [L+1][6]  = min0, min1, min2, -max0, -max1, -max2 (inclusive max, INT32_MAX

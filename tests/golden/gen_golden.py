@@ -1,0 +1,98 @@
+"""Generate the golden fixtures under tests/golden/ (run from the repo root):
+
+    python tests/golden/gen_golden.py
+
+Inputs come from the repo's own deterministic generator; expected outputs come from the oracle
+(oracle/sia_oracle.py = the reference's per-label scipy.ndimage algorithm restated for Python 3,
+oracle/onepass.py = the exact-integer spec).  Nothing is read from /root/reference.  The reference
+cannot be imported here (Python 2 + openalea), so these vectors pin "the restatement on scipy
+1.15.3 / numpy 2.2.6", see DESIGN.md.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+from oracle import onepass                       # noqa: E402
+from oracle.sia_oracle import OracleSIA, DICT    # noqa: E402
+from tissue_analysis_amd import synth            # noqa: E402
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def csr(d, keys):
+    ptr, idx = [0], []
+    for k in keys:
+        idx.extend(sorted(int(v) for v in d[k]))
+        ptr.append(len(idx))
+    return np.asarray(ptr, dtype=np.int64), np.asarray(idx, dtype=np.int64)
+
+
+def config1():
+    c = synth.CONFIGS["C1"]
+    vol = synth.voronoi_labels(c["dims"], c["n_cells"], c["seed"], np.dtype(c["dtype"]))
+    vs = synth.PARITY_VOXELSIZE
+    ints = onepass.extract(vol)
+    sia = OracleSIA(vol, ignoredlabels=0, return_type=DICT, background=1, voxelsize=vs)
+    labels = sia.labels()
+    nb_all = sia.neighbors()                     # labels + background, like the reference
+    keys = sorted(nb_all)
+    nptr, nidx = csr(nb_all, keys)
+    bary = sia.center_of_mass(labels, real=True)
+    vol_real = sia.volume(labels, real=True)
+    vecs, vals = sia.inertia_axis(labels, real=True)
+    vecs_v, vals_v = sia.inertia_axis(labels, real=False)
+    cov = np.stack([sia.covariance(l) for l in labels])
+    walls = sia.wall_areas(real=True)
+    wkeys = sorted(walls)
+    out = dict(
+        volume_sha256=np.frombuffer(hashlib.sha256(vol.tobytes()).digest(), dtype=np.uint8),
+        shape=np.asarray(vol.shape), voxelsize=np.asarray(vs), max_label=np.asarray(ints["max_label"]),
+        count=ints["count"], bbox=ints["bbox"], sum1=ints["sum1"], sum2=ints["sum2"],
+        pair_lo=ints["pair_lo"], pair_hi=ints["pair_hi"], pair_faces=ints["pair_faces"],
+        labels=np.asarray(labels), barycenter_real=np.stack([bary[l] for l in labels]),
+        volume_real=np.asarray([vol_real[l] for l in labels]),
+        covariance=cov, inertia_values_real=np.stack([vals[l] for l in labels]),
+        inertia_values_voxel=np.stack([vals_v[l] for l in labels]),
+        inertia_vectors=np.stack([np.stack(vecs[l]) for l in labels]),
+        neighbor_keys=np.asarray(keys), neighbor_ptr=nptr, neighbor_idx=nidx,
+        wall_keys=np.asarray(wkeys, dtype=np.int64).reshape(-1, 2),
+        wall_area_real=np.asarray([walls[k] for k in wkeys]),
+        border=np.asarray(sia.labels_at_stack_margins()),
+        first_layer=np.asarray(sia.cell_first_layer()),
+    )
+    np.savez_compressed(os.path.join(HERE, "config1_128x128x64_u16.npz"), **out)
+    print("config1: %d labels, %d pairs, %d walls" % (len(labels), ints["pair_lo"].size, len(wkeys)))
+
+
+def adversarial():
+    """Tiny volumes for the edge cases of SURVEY.md §4(3); inputs are stored with the outputs."""
+    rng = np.random.default_rng(123)
+    cases = {}
+    a = np.ones((5, 6, 7), dtype=np.uint16); a[2, 3, 4] = 9; a[0, 0, 0] = 40000; a[4, 5, 6] = 65535
+    cases["single_voxels_and_corners_u16"] = a
+    b = rng.integers(0, 4, size=(6, 5, 9)).astype(np.uint32) * 70000        # ids 0, 70000, 140000, 210000
+    cases["sparse_ids_above_65535_u32"] = b
+    c = np.zeros((4, 4, 4), dtype=np.uint16); c[1:3, 1:3, 1:3] = 3
+    cases["label_zero_surrounds_cube"] = c
+    d = (np.arange(3 * 4 * 5) % 7 + 1).astype(np.uint16).reshape(3, 4, 5)
+    cases["striped_small"] = d
+    e = rng.integers(1, 30, size=(9, 3, 70)).astype(np.uint32)
+    cases["noise_u32"] = e
+    out = {}
+    for name, vol in cases.items():
+        r = onepass.extract(vol)
+        out[name + "__volume"] = vol
+        for k in ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces"):
+            out[name + "__" + k] = r[k]
+    np.savez_compressed(os.path.join(HERE, "adversarial_small.npz"), **out)
+    print("adversarial: %d cases" % len(cases))
+
+
+if __name__ == "__main__":
+    config1()
+    adversarial()

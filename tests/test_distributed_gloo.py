@@ -1,0 +1,83 @@
+"""The multi-GPU exchange step on CPU: 2 gloo processes, each holding the accumulators of its
+Z-slab (+ one halo plane) in the device layout; after the collectives every rank must hold exactly
+the accumulators of the unsharded volume (bit-exact)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def _worker(rank, world, port, dims, n_cells, seed, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import onepass
+        from tissue_analysis_amd import distributed as tad, synth
+        vol = synth.voronoi_labels(dims, n_cells, seed, np.uint16)
+        whole = onepass.extract(vol)
+        L = whole["max_label"]
+        lo, hi = tad.slab_range(dims[0], world, rank)
+        halo = 1 if lo > 0 else 0
+        part = onepass.extract(vol[lo - halo:hi], max_label=L, origin=(lo - halo, 0, 0), own_first_plane=not halo)
+        sums, boxes = tad.to_device_layout(part)
+        sums_t, boxes_t = torch.from_numpy(sums), torch.from_numpy(boxes)
+        tad.allreduce_accumulators(sums_t, boxes_t)
+        merged = tad.from_device_layout(sums_t.numpy(), boxes_t.numpy())
+        keys = (part["pair_lo"].astype(np.int64) << 32) | part["pair_hi"].astype(np.int64)
+        kall, fall, m = tad.allgather_pairs(torch.from_numpy(keys), torch.from_numpy(part["pair_faces"].astype(np.int64)))
+        kall, fall = kall.numpy(), fall.numpy()
+        keep = kall != tad.EMPTY_KEY
+        plo, phi, pf = onepass.compact_pairs(kall[keep] >> 32, kall[keep] & 0xFFFFFFFF, fall[keep])
+        ok = all(np.array_equal(merged[k], whole[k]) for k in ("count", "bbox", "sum1", "sum2"))
+        ok = ok and np.array_equal(plo, whole["pair_lo"]) and np.array_equal(phi, whole["pair_hi"]) \
+            and np.array_equal(pf, whole["pair_faces"])
+        out_q.put((rank, bool(ok), int(m)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dims,n_cells", [((21, 16, 24), 14), ((8, 20, 20), 10)])
+def test_two_rank_reduce_equals_unsharded(dims, n_cells):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, n_cells, 31, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == [0, 1]
+    assert all(r[1] for r in results), results
+
+
+def test_slab_ranges_partition_the_axis():
+    from tissue_analysis_amd import distributed as tad
+    for n0 in (1, 7, 64, 1000):
+        for world in (1, 2, 3, 8):
+            spans = [tad.slab_range(n0, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n0
+            assert all(a[1] == b[0] for a, b in zip(spans[:-1], spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_device_layout_roundtrip():
+    from oracle import onepass
+    from tissue_analysis_amd import distributed as tad, synth
+    vol = synth.voronoi_labels((10, 12, 14), 6, 3, np.uint16)
+    r = onepass.extract(vol, max_label=int(vol.max()) + 3)      # trailing absent labels
+    back = tad.from_device_layout(*tad.to_device_layout(r))
+    for k in ("count", "bbox", "sum1", "sum2"):
+        assert np.array_equal(back[k], r[k]), k

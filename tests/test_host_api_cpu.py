@@ -1,0 +1,100 @@
+"""Host logic of the drop-in class on CPU: the integer accumulators are injected (computed by the
+oracle's one-pass spec, as the GPU would produce them) and every public method is compared with the
+oracle's mirror of the reference API.  No voxel is scanned by the product here."""
+import numpy as np
+import pytest
+
+from oracle import onepass
+from oracle.sia_oracle import OracleSIA
+from oracle import sia_oracle
+from tissue_analysis_amd import DICT, LIST, NPLIST, Extraction, SpatialImage, SpatialImageAnalysis, SpatialImageAnalysis3D
+from tissue_analysis_amd import synth
+
+from api_compare import compare_api
+from helpers import random_blocks, voronoi
+
+VS = synth.PARITY_VOXELSIZE
+
+
+def injected(vol):
+    return Extraction.from_arrays(vol.shape if vol.ndim == 3 else vol.shape + (1,), onepass.extract(vol))
+
+
+CASES = [
+    ("voronoi", lambda: voronoi((30, 26, 34), 20, 21, np.uint16), dict(ignoredlabels=0, background=1)),
+    ("voronoi_no_bg", lambda: voronoi((22, 24, 20), 12, 22, np.uint32, ellipsoid=False), dict()),
+    ("blocks_with_zero", lambda: random_blocks((14, 12, 18), 30, 23, np.uint16), dict(ignoredlabels=0)),
+]
+
+
+@pytest.mark.parametrize("name,make,kw", CASES, ids=[c[0] for c in CASES])
+def test_api_matches_reference_mirror(name, make, kw):
+    vol = make()
+    img = SpatialImage(vol, voxelsize=VS)
+    with pytest.warns(UserWarning) if "background" not in kw else _nullcontext():
+        sia = SpatialImageAnalysis3D(img, return_type=DICT, extraction=injected(vol), **kw)
+    ref = OracleSIA(vol, return_type=sia_oracle.DICT, voxelsize=VS, **kw)
+    compare_api(sia, ref)
+
+
+class _nullcontext(object):
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False
+
+
+def test_docstring_example_through_the_dropin_class():
+    """SIA:344-353 ... 1211-1226: the 4x6 example, 2D image handled as (4, 6, 1)."""
+    a = np.array([[1, 2, 7, 7, 1, 1], [1, 6, 5, 7, 3, 3], [2, 2, 1, 7, 3, 3], [1, 1, 1, 4, 1, 1]], dtype=np.uint16)
+    with pytest.warns(UserWarning):
+        sia = SpatialImageAnalysis(a, extraction=injected(a[:, :, None]))
+    assert sia.labels() == [1, 2, 3, 4, 5, 6, 7] and sia.nb_labels() == 7
+    np.testing.assert_allclose(sia.center_of_mass(7), [0.75, 2.75, 0.0])
+    assert sia.boundingbox(7) == (slice(0, 3), slice(2, 4), slice(0, 1))
+    assert sia.neighbors(7) == [1, 2, 3, 4, 5]
+    assert sia.neighbors() == {1: [2, 3, 4, 5, 6, 7], 2: [1, 6, 7], 3: [1, 7], 4: [1, 7], 5: [1, 6, 7],
+                               6: [1, 2, 5], 7: [1, 2, 3, 4, 5]}
+    assert sia.cell_wall_area(7, 2) == 1.0
+    assert sia.cell_wall_area(7, [2, 5]) == {(2, 7): 1.0, (5, 7): 2.0}
+    assert sia.wall_areas() == {(1, 2): 5.0, (1, 3): 4.0, (1, 4): 2.0, (1, 5): 1.0, (1, 6): 1.0, (1, 7): 2.0,
+                                (2, 6): 2.0, (2, 7): 1.0, (3, 7): 2.0, (4, 7): 1.0, (5, 6): 1.0, (5, 7): 2.0}
+    v = sia.volume()
+    assert [v[l] for l in range(1, 8)] == [10.0, 3.0, 4.0, 1.0, 1.0, 1.0, 4.0]
+
+
+def test_return_types_and_label_requests():
+    vol = voronoi((16, 18, 20), 9, 24, np.uint16)
+    x = injected(vol)
+    for rt, ort in ((NPLIST, sia_oracle.NPLIST), (LIST, sia_oracle.LIST), (DICT, sia_oracle.DICT)):
+        sia = SpatialImageAnalysis3D(vol, return_type=rt, background=1, extraction=x)
+        ref = OracleSIA(vol, return_type=ort, background=1)
+        a, b = sia.volume(), ref.volume()
+        if rt == DICT:
+            assert a == b
+        else:
+            np.testing.assert_allclose(np.asarray(a), np.asarray(b))
+            assert type(a) is type(b)
+        assert sia.convert_return([1, 2], 5) == [1, 2]
+    sia = SpatialImageAnalysis3D(vol, background=1, extraction=x)
+    labs = sia.labels()
+    assert sia.label_request(None) == labs and sia.label_request("all") == labs
+    assert sia.label_request(labs[0]) == [labs[0]]
+    assert sia.label_request([labs[2], labs[0], 10 ** 6]) == sorted([labs[0], labs[2]])
+    assert sia.label_request("L1") == sia.cell_first_layer()
+    with pytest.raises(ValueError):
+        sia.label_request(3.5)
+    with pytest.raises(ValueError):
+        SpatialImageAnalysis3D(vol, background=1.5, extraction=x)
+    before = len(labs)
+    sia.add2ignoredlabels(labs[0])
+    assert sia.nb_labels() == before - 1 and labs[0] not in sia.labels()
+    sia.consideronlylabels(labs[1:3])
+    assert sia.labels() == labs[1:3]
+
+
+def test_missing_background_warns_like_the_reference(capsys):
+    vol = voronoi((10, 10, 12), 4, 25, np.uint16, ellipsoid=False)
+    SpatialImageAnalysis3D(vol, background=60000, extraction=injected(vol))
+    assert "has not been detected" in capsys.readouterr().out

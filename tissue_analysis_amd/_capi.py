@@ -25,7 +25,7 @@ SYMBOLS = (
     "ta_version", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_synchronize", "ta_volume_set",
     "ta_volume_set_device", "ta_volume_max_label", "ta_extract", "ta_get_labels",
-    "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_bind_accumulators",
+    "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_debug_counters", "ta_bind_accumulators",
     "ta_accumulators_device", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge", "ta_synth_voronoi",
     "ta_device_malloc", "ta_device_free", "ta_memcpy_d2h", "ta_memcpy_h2d",
 )
@@ -70,6 +70,7 @@ def load():
         "ta_adjacency_size": (ci, [vp, P(i64)]),
         "ta_adjacency_get": (ci, [vp, vp, vp, vp]),
         "ta_timing": (ci, [vp, P(ctypes.c_double), P(ctypes.c_double), P(ctypes.c_double), P(u64)]),
+        "ta_debug_counters": (ci, [vp, P(u32)]),
         "ta_bind_accumulators": (ci, [vp, vp, vp, u32]),
         "ta_accumulators_device": (ci, [vp, P(vp), P(vp), P(u32)]),
         "ta_adjacency_device": (ci, [vp, P(vp), P(vp), P(i64)]),
@@ -218,6 +219,11 @@ class Context(object):
         _check(self._lib.ta_timing(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(t),
                                    ctypes.byref(nbytes)))
         return dict(ms_sweep=a.value, ms_adjacency=b.value, ms_total=t.value, bytes_read=nbytes.value)
+
+    def debug_counters(self):
+        out = (ctypes.c_uint32 * 8)()
+        _check(self._lib.ta_debug_counters(self._h, out))
+        return dict(range_flag=out[0], pair_overflow=out[1], label_spills=out[2], pair_spills=out[3])
 
     # -- multi-GPU views
     def bind_accumulators(self, sums_ptr, boxes_ptr, max_label, keep=None):

@@ -77,8 +77,8 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
 }
 
 // ---- strip loads ---------------------------------------------------------------------------
-template <typename T, int VPL, bool EDGE>
-__device__ __forceinline__ void load_strip(const T* row, bool row_ok, int64_t c, int64_t n2,
+template <typename T, int VPL>
+__device__ __forceinline__ void load_strip(const bool EDGE, const T* row, bool row_ok, int64_t c, int64_t n2,
                                            uint32_t (&dst)[VPL]) {
     if (!EDGE) {
         const uint4 x = *reinterpret_cast<const uint4*>(row + c);
@@ -96,6 +96,27 @@ __device__ __forceinline__ void load_strip(const T* row, bool row_ok, int64_t c,
     }
 }
 
+// ---- rare spill paths, kept out of line so they do not bloat the hot loops ------------------
+__device__ __noinline__ void label_spill_global(uint64_t* sums, int32_t* boxes, uint32_t* flags,
+                                                uint32_t max_label, uint32_t label, const uint64_t* sv,
+                                                int ns, uint32_t mn0, uint32_t mx0, uint32_t mn1,
+                                                uint32_t mx1, uint32_t mn2, uint32_t mx2) {
+    atomicAdd(&flags[FLAG_LDS_LABEL_SPILL], 1u);
+    if (label > max_label) { atomicOr(&flags[FLAG_RANGE], 1u); return; }
+    unsigned long long* row = (unsigned long long*)&sums[(uint64_t)label * NSUM];
+    for (int k = 0; k < ns; ++k) atomicAdd(row + k, (unsigned long long)sv[k]);
+    int32_t* box = &boxes[(uint64_t)label * NBOX];
+    atomicMin(box + 0, (int32_t)mn0); atomicMin(box + 3, -(int32_t)mx0);
+    atomicMin(box + 1, (int32_t)mn1); atomicMin(box + 4, -(int32_t)mx1);
+    atomicMin(box + 2, (int32_t)mn2); atomicMin(box + 5, -(int32_t)mx2);
+}
+
+__device__ __noinline__ void pair_spill_global(PairTable pt, uint32_t* flags, uint32_t lo, uint32_t hi,
+                                               uint32_t axis) {
+    atomicAdd(&flags[FLAG_LDS_PAIR_SPILL], 1u);
+    pair_add_global(pt, lo, hi, axis == 0, axis == 1, axis == 2, flags);
+}
+
 // ---- workgroup-shared LDS tables -----------------------------------------------------------
 template <bool MOM2, typename LDS>
 __device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, uint32_t label,
@@ -104,6 +125,7 @@ __device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, uint32
     constexpr int NS = MOM2 ? 10 : 4;
     uint32_t h = hash_u32(label) & (LSLOTS - 1);
     int slot = -1;
+#pragma nounroll
     for (int probe = 0; probe < LPROBE; ++probe) {
         uint32_t k = S.lkeys[h];
         if (k == INVALID_LABEL) {
@@ -122,15 +144,7 @@ __device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, uint32
         atomicMin(box + 1, mn1); atomicMax(box + 4, mx1);
         atomicMin(box + 2, mn2); atomicMax(box + 5, mx2);
     } else {                                       // table full: straight to the global rows
-        atomicOr(&A.flags[FLAG_LDS_LABEL_SPILL], 1u);
-        if (label > A.max_label) { atomicOr(&A.flags[FLAG_RANGE], 1u); return; }
-        unsigned long long* row = (unsigned long long*)&A.sums[(uint64_t)label * NSUM];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) atomicAdd(row + k, (unsigned long long)sv[k]);
-        int32_t* box = &A.boxes[(uint64_t)label * NBOX];
-        atomicMin(box + 0, (int32_t)mn0); atomicMin(box + 3, -(int32_t)mx0);
-        atomicMin(box + 1, (int32_t)mn1); atomicMin(box + 4, -(int32_t)mx1);
-        atomicMin(box + 2, (int32_t)mn2); atomicMin(box + 5, -(int32_t)mx2);
+        label_spill_global(A.sums, A.boxes, A.flags, A.max_label, label, sv, NS, mn0, mx0, mn1, mx1, mn2, mx2);
     }
 }
 
@@ -141,6 +155,7 @@ __device__ __forceinline__ void lds_pair_add(const SweepArgs& A, LDS& S, uint32_
     const uint64_t key = ((uint64_t)lo << 32) | hi;
     uint32_t h = hash_pair(lo, hi) & (PSLOTS - 1);
     int slot = -1;
+#pragma nounroll
     for (int probe = 0; probe < PPROBE; ++probe) {
         uint64_t k = S.pkeys[h];
         if (k == EMPTY_KEY) {
@@ -154,8 +169,7 @@ __device__ __forceinline__ void lds_pair_add(const SweepArgs& A, LDS& S, uint32_
     if (slot >= 0) {
         atomicAdd(&S.pcnt[slot * 3 + axis], 1u);
     } else {
-        atomicOr(&A.flags[FLAG_LDS_PAIR_SPILL], 1u);
-        pair_add_global(A.pairs, lo, hi, axis == 0, axis == 1, axis == 2, A.flags);
+        pair_spill_global(A.pairs, A.flags, lo, hi, axis);
     }
 }
 
@@ -166,8 +180,8 @@ __device__ __forceinline__ uint64_t range_sum2(uint64_t x0, uint64_t n) {
 }
 
 // ---- the wave body ---------------------------------------------------------------------------
-template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, typename LDS>
-__device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const int lane, const int w,
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, typename LDS>
+__device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const bool EDGE, const int lane, const int w,
                                            const int64_t c_tile0, const int64_t b_tile0,
                                            const int64_t p_lo, const int64_t p_hi) {
     constexpr int TC = 64 * VPL;
@@ -195,7 +209,7 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const int
             const int64_t b = b_wave0 + r;
             const bool row_ok = b < n1;
             const T* row = pbase + (EDGE ? (row_ok ? b : 0) : b) * n2;
-            load_strip<T, VPL, EDGE>(row, row_ok, c0, n2, d[r]);
+            load_strip<T, VPL>(EDGE, row, row_ok, c0, n2, d[r]);
         }
     };
     auto load_halo = [&](int64_t p, uint32_t (&dup)[VPL], uint32_t (&dl)[RB]) {
@@ -211,7 +225,7 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const int
         if (has_up) {
             const bool row_ok = (b_wave0 - 1) < n1;
             const T* row = pbase + (EDGE ? (row_ok ? (b_wave0 - 1) : 0) : (b_wave0 - 1)) * n2;
-            load_strip<T, VPL, EDGE>(row, row_ok, c0, n2, dup);
+            load_strip<T, VPL>(EDGE, row, row_ok, c0, n2, dup);
         }
     };
     auto store_rows = [&](int buf, const uint32_t (&d)[RB][VPL]) {
@@ -425,17 +439,15 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const int
         // the run consumer (QCAP codes per window)
         const int lbuf = buf ^ 1;
         if (!prev_in_lds) store_rows(lbuf, prev);
+#pragma nounroll
+        for (int rq = 0; rq < RB * (VPL / 4); ++rq) {      // runtime loop: one consumer site
+            const uint32_t r = (uint32_t)rq / (VPL / 4), q = (uint32_t)rq % (VPL / 4);
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int r = 0; r < RB; ++r) {
-#pragma unroll
-            for (int q = 0; q < VPL / 4; ++q) {
-                __builtin_amdgcn_wave_barrier();
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    W.rq[j * 64 + lane] = ((uint32_t)lane * VPL + 4 * q + j) | ((uint32_t)r << 10);
-                __builtin_amdgcn_wave_barrier();
-                consume_runs(QCAP, lbuf, last, false);
-            }
+            for (int j = 0; j < 4; ++j)
+                W.rq[j * 64 + lane] = ((uint32_t)lane * VPL + 4 * q + j) | (r << 10);
+            __builtin_amdgcn_wave_barrier();
+            consume_runs(QCAP, lbuf, last, false);
         }
     }
 }
@@ -475,8 +487,7 @@ __global__ void __launch_bounds__(WAVES * 64) sweep_kernel(SweepArgs A) {
 
     if (p_lo < p_hi) {
         const bool interior = A.vec_ok && (c_tile0 + TC <= A.n2) && (b_tile0 + (int64_t)(w + 1) * RB <= A.n1);
-        if (interior) wave_sweep<T, VPL, RB, ADJ, MOM2, false>(A, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
-        else          wave_sweep<T, VPL, RB, ADJ, MOM2, true>(A, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
+        wave_sweep<T, VPL, RB, ADJ, MOM2>(A, S, !interior, lane, w, c_tile0, b_tile0, p_lo, p_hi);
     }
     __syncthreads();
 
@@ -505,7 +516,7 @@ __global__ void __launch_bounds__(WAVES * 64) sweep_kernel(SweepArgs A) {
     }
 }
 
-int sweep_default_tile_planes() { return 32; }
+int sweep_default_tile_planes() { return 32; }   // 64 planes start to overflow the 128-slot label table
 
 template <typename T, int VPL, int RB>
 static void launch_sweep_t(hipStream_t s, const SweepArgs& a, uint32_t fm) {

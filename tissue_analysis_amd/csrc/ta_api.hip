@@ -502,6 +502,16 @@ TA_API int ta_timing(ta_ctx* c, double* ms_sweep, double* ms_adjacency, double* 
     return TA_OK;
 }
 
+TA_API int ta_debug_counters(ta_ctx* c, uint32_t out[8]) {
+    if (!c || !out) return fail(TA_EINVAL, "NULL argument");
+    if (!c->extracted) return fail(TA_EINVAL, "no extraction has been run on this context");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    TA_HIP(hipStreamSynchronize(c->stream));
+    for (int i = 0; i < 8; ++i) out[i] = i < ta::NFLAGS ? c->h_small[i] : 0u;
+    return TA_OK;
+}
+
 TA_API int ta_accumulators_device(ta_ctx* c, void** sums_dev, void** boxes_dev, uint32_t* max_label) {
     if (!c) return fail(TA_EINVAL, "ctx is NULL");
     if (!c->extracted) return fail(TA_EINVAL, "no extraction has been run on this context");
