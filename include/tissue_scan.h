@@ -118,8 +118,9 @@ TA_API int ta_timing(ta_ctx* ctx, double* ms_sweep, double* ms_adjacency, double
 
 /* Diagnostics of the last ta_extract: out[0] = label-range flag, out[1] = adjacency-table overflow
  * flag, out[2] = run records that missed the workgroup LDS label table (went to global atomics),
- * out[3] = face records that missed the LDS pair table, out[4..7] reserved. */
-TA_API int ta_debug_counters(ta_ctx* ctx, uint32_t out[8]);
+ * out[3] = face records that missed the LDS pair table, out[4..15] reserved (cycle stamps of
+ * diagnostic builds). */
+TA_API int ta_debug_counters(ta_ctx* ctx, uint32_t out[16]);
 
 /* ---- device-side views for the multi-GPU reduce (RCCL runs on these in place) -------------
  * sums  : uint64 [L+1][10] = count, s0, s1, s2, s00, s01, s02, s11, s12, s22   (reduce: SUM)

@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtissue_scan.so")
+LIB_PATH = os.environ.get("TISSUE_SCAN_LIB") or os.path.join(_HERE, "libtissue_scan.so")
 
 TA_OK, TA_EINVAL, TA_EHIP, TA_ENOMEM, TA_ERANGE, TA_ECAPACITY, TA_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
 F_VOLUME, F_BBOX, F_MOMENT1, F_MOMENT2, F_ADJACENCY = 1, 2, 4, 8, 16
@@ -221,9 +221,12 @@ class Context(object):
         return dict(ms_sweep=a.value, ms_adjacency=b.value, ms_total=t.value, bytes_read=nbytes.value)
 
     def debug_counters(self):
-        out = (ctypes.c_uint32 * 8)()
+        out = (ctypes.c_uint32 * 16)()
         _check(self._lib.ta_debug_counters(self._h, out))
-        return dict(range_flag=out[0], pair_overflow=out[1], label_spills=out[2], pair_spills=out[3])
+        d = dict(range_flag=out[0], pair_overflow=out[1], label_spills=out[2], pair_spills=out[3])
+        if any(out[8:16]):
+            d["stamps"] = [int(v) for v in out[8:16]]
+        return d
 
     # -- multi-GPU views
     def bind_accumulators(self, sums_ptr, boxes_ptr, max_label, keep=None):

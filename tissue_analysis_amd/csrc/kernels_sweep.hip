@@ -6,58 +6,87 @@
 // behind neighbors / cell_wall_area / wall_areas (SIA:538-660, 908-993).
 //
 // Work decomposition (memory axes: 0 slowest ... 2 fastest)
-//   workgroup = 4 waves stacked along axis 1; wave tile = RB rows x (64 lanes * VPL voxels)
-//   along axis 2; the workgroup walks `tile_planes` planes along axis 0, next plane prefetched
-//   into registers with 16-byte loads while the current one is processed.
-//   Per plane ("step") a wave
-//     1. compares every voxel with its three predecessors entirely in registers (axis 0: the
-//        lane's registers from the previous plane; axis 1: the row above in the same lane + one
-//        halo row; axis 2: the previous voxel of the strip + one DPP wave shift) and packs the
-//        results into per-lane event bitmaps -- static register indices only;
-//     2. if no lane saw an event (interior of a cell, background) the step ends here: nothing
-//        is written, runs simply continue (this is ~60 % of a tissue-in-ellipsoid volume);
-//     3. otherwise stages the plane tile (+halo row/column) in LDS, prefix-scans the per-lane
-//        event counts with DPP and lets every lane append 4-byte POSITION CODES of its events to
-//        two per-wave LDS queues (faces / closed column runs);
-//     4. consumes the queues 64 records at a time with every lane busy: a consumer lane decodes
-//        its code, fetches the voxel and its neighbour from the LDS tile and updates two
-//        workgroup-shared LDS hash tables with LDS atomics:
-//           label -> {10 x u64 moment sums, bbox}      (one update per closed column run: a run
-//                                                      (label, a0..a1, b, c) gives all ten
-//                                                      moments in closed form)
-//           (lo,hi) -> 3 x u32 face counters.
-//   A wave tile that never saw an event is one label: it contributes a closed-form box.
-//   The tables are flushed once per workgroup tile with global atomics (u64 add / i32 min);
-//   integer sums and minima make the result independent of tiling, scheduling and order.
+//   workgroup = WAVES waves stacked along axis 1; wave tile = RB rows x (64 lanes * VPL voxels)
+//   along axis 2; each lane keeps its RB x VPL voxels of the current plane in VGPRs (16-byte
+//   loads, next plane prefetched) and the workgroup walks `tile_planes` planes along axis 0.
+//   * Neighbours never leave the register file: axis 0 = the lane's registers from the previous
+//     plane (they double as the label of the column's open run), axis 1 = the row above in the
+//     same lane (+ one halo row per wave), axis 2 = the previous voxel of the strip (+ one DPP
+//     wave shift for voxel 0).
+//   * Every (voxel slot, axis) is one straight-line BLOCK: v_cmp gives the 64-lane event mask for
+//     free; when it is non-zero the firing lanes append an 8-byte record {voxel, neighbour|axis}
+//     (faces) and, for axis 0, {closed label, column, first plane, length} (runs) to small per-wave
+//     LDS rings at mask-prefix (mbcnt) offsets.  Empty blocks cost one compare and one branch --
+//     that is the whole cost of the ~60 % of a tissue-in-ellipsoid volume that is background or
+//     cell interior.
+//   * The rings are consumed 64 records at a time with every lane busy.  A closed column run
+//     (label, a0, n, b, c) yields all ten moments in closed form in TILE-LOCAL coordinates, two
+//     32-bit sums per u64 LDS atomic, into a workgroup-shared LDS hash table; faces go to a
+//     second LDS hash keyed by (lo,hi) with three counters.
+//   * The wave body is a resumable fall-through `switch`: blocks run back to back and there is
+//     exactly ONE consumer site, entered when a ring holds >= 64 records.
+//   * Tables are flushed once per workgroup tile with global atomics (u64 add / i32 min) after
+//     shifting the local sums to global coordinates; integer sums and minima make the result
+//     independent of tiling, scheduling and order.
 //   No MFMA anywhere: integer compare/reduce work bound by the HBM read of the volume.
 #include "ta_kernels.h"
 
 namespace ta {
 
-constexpr int WAVES = 4;          // waves per workgroup, stacked along axis 1
-constexpr int QCAP = 256;         // per-wave queue capacity (position codes) = emission window
-constexpr int LSLOTS = 128;       // label table slots per workgroup
-constexpr int PSLOTS = 512;       // pair table slots per workgroup
+#ifndef TA_ABLATE
+#define TA_ABLATE 0     // experiments only: 1 = records are produced but not consumed
+#endif
+#ifndef TA_WAVES
+#define TA_WAVES 4
+#endif
+#ifndef TA_RB32
+#define TA_RB32 4
+#endif
+#ifndef TA_QCAP
+#define TA_QCAP 256
+#endif
+#ifndef TA_PSLOTS
+#define TA_PSLOTS 512
+#endif
+#ifndef TA_LSLOTS
+#define TA_LSLOTS 128
+#endif
+#ifndef TA_PREFETCH
+#define TA_PREFETCH 1
+#endif
+#ifndef TA_MINWAVES
+#define TA_MINWAVES 3             // waves per SIMD the register allocator must leave room for
+#endif
+constexpr int WAVES = TA_WAVES;   // waves per workgroup, stacked along axis 1
+constexpr int QCAP = TA_QCAP;     // per-wave ring capacity (records); one block adds <= 64
+constexpr int LSLOTS = TA_LSLOTS; // label table slots per workgroup
+constexpr int PSLOTS = TA_PSLOTS; // pair table slots per workgroup
 constexpr int LPROBE = 16;        // max probes before spilling to global atomics
 constexpr int PPROBE = 32;
+constexpr int MAX_TILE_PLANES = 64;
+constexpr uint32_t LABEL_LIMIT = 1u << 28;    // max_label < 2^28: the two top bits of a record word are free
 
-template <int RB, int TC>
 struct __attribute__((aligned(16))) WaveLds {
-    static constexpr int RS = TC + 4;                 // row stride (dwords); dword 3 = left halo voxel
-    uint32_t tile[2][(RB + 1) * RS];                  // [plane parity][row 0 = halo row above | rows 1..RB]
-    uint32_t fq[QCAP];                                // face events: position codes
-    uint32_t rq[QCAP];                                // closed runs: position codes
-    uint8_t a0[RB * TC];                              // first plane (tile-local, < 256) of each column's open run
+    uint2 fq[QCAP];               // faces: {voxel, neighbour | axis << 30}
+    uint2 rq[QCAP];               // runs : {label, c_loc | b_loc << 10 | a0 << 14 | n << 20}
 };
 
-template <int NS, int RB, int TC>
+// Workgroup tables.  Moments are kept in TILE-LOCAL coordinates (a < 64 planes, b < 16 rows,
+// c < 512 columns, so N <= 2^19 voxels of one label per tile) and two sums share one u64 LDS
+// atomic with a free 32/32 split; every half is a hard maximum below 2^32:
+//   w0 = N | Sb<<32   w1 = Sa | Sc<<32   w2 = Saa | Sab<<32   w3 = Sbb | Sbc<<32   w4 = Sac   w5 = Scc
+// They are unpacked and shifted to global coordinates (exact u64) once per tile at the flush.
+template <int NW>
 struct __attribute__((aligned(16))) SweepLds {
-    WaveLds<RB, TC> wave[WAVES];
-    uint64_t lsum[LSLOTS * NS];
+    WaveLds wave[WAVES];
+    uint64_t lsum[LSLOTS * NW];
     uint64_t pkeys[PSLOTS];
+    uint32_t lbox[LSLOTS * 8];    // per slot: min a,b,c | max a,b,c (tile-local) | 2 pad
     uint32_t lkeys[LSLOTS];
-    uint32_t lbox[LSLOTS * 6];    // min0,min1,min2 (u32 min) | max0,max1,max2 (u32 max), global coords
     uint32_t pcnt[PSLOTS * 3];
+#ifdef TA_LDS_PAD
+    uint32_t pad_[TA_LDS_PAD];
+#endif
 };
 
 __device__ __forceinline__ uint32_t lane_shr1(uint32_t src, uint32_t lane0_value) {
@@ -65,15 +94,8 @@ __device__ __forceinline__ uint32_t lane_shr1(uint32_t src, uint32_t lane0_value
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)src, 0x138, 0xf, 0xf, false);
 }
 
-// inclusive add-scan over the 64 lanes of a wave with DPP row shifts + row broadcasts
-__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, true);   // row_bcast:15 -> rows 1,3
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, true);   // row_bcast:31 -> rows 2,3
-    return x;
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
 // ---- strip loads ---------------------------------------------------------------------------
@@ -96,33 +118,52 @@ __device__ __forceinline__ void load_strip(const bool EDGE, const T* row, bool r
     }
 }
 
+// local sums of one label contribution (tile-local coordinates)
+struct LocalSums { uint64_t n, sa, sb, sc, saa, sab, sac, sbb, sbc, scc; };
+
+// shift tile-local sums to global coordinates (origin A0,B0,C0): exact u64
+__device__ __forceinline__ void local_to_global(const LocalSums& L, uint64_t A0, uint64_t B0, uint64_t C0,
+                                                uint64_t (&g)[NSUM]) {
+    g[0] = L.n;
+    g[1] = L.sa + L.n * A0; g[2] = L.sb + L.n * B0; g[3] = L.sc + L.n * C0;
+    g[4] = L.saa + 2 * A0 * L.sa + L.n * A0 * A0;
+    g[5] = L.sab + A0 * L.sb + B0 * L.sa + L.n * A0 * B0;
+    g[6] = L.sac + A0 * L.sc + C0 * L.sa + L.n * A0 * C0;
+    g[7] = L.sbb + 2 * B0 * L.sb + L.n * B0 * B0;
+    g[8] = L.sbc + B0 * L.sc + C0 * L.sb + L.n * B0 * C0;
+    g[9] = L.scc + 2 * C0 * L.sc + L.n * C0 * C0;
+}
+
 // ---- rare spill paths, kept out of line so they do not bloat the hot loops ------------------
 __device__ __noinline__ void label_spill_global(uint64_t* sums, int32_t* boxes, uint32_t* flags,
-                                                uint32_t max_label, uint32_t label, const uint64_t* sv,
-                                                int ns, uint32_t mn0, uint32_t mx0, uint32_t mn1,
-                                                uint32_t mx1, uint32_t mn2, uint32_t mx2) {
+                                                uint32_t max_label, uint32_t label, const LocalSums* L,
+                                                uint64_t A0, uint64_t B0, uint64_t C0, const uint32_t* box) {
     atomicAdd(&flags[FLAG_LDS_LABEL_SPILL], 1u);
     if (label > max_label) { atomicOr(&flags[FLAG_RANGE], 1u); return; }
+    uint64_t g[NSUM];
+    local_to_global(*L, A0, B0, C0, g);
     unsigned long long* row = (unsigned long long*)&sums[(uint64_t)label * NSUM];
-    for (int k = 0; k < ns; ++k) atomicAdd(row + k, (unsigned long long)sv[k]);
-    int32_t* box = &boxes[(uint64_t)label * NBOX];
-    atomicMin(box + 0, (int32_t)mn0); atomicMin(box + 3, -(int32_t)mx0);
-    atomicMin(box + 1, (int32_t)mn1); atomicMin(box + 4, -(int32_t)mx1);
-    atomicMin(box + 2, (int32_t)mn2); atomicMin(box + 5, -(int32_t)mx2);
+    for (int k = 0; k < NSUM; ++k) if (g[k]) atomicAdd(row + k, (unsigned long long)g[k]);
+    int32_t* gb = &boxes[(uint64_t)label * NBOX];
+    atomicMin(gb + 0, (int32_t)(A0 + box[0])); atomicMin(gb + 3, -(int32_t)(A0 + box[3]));
+    atomicMin(gb + 1, (int32_t)(B0 + box[1])); atomicMin(gb + 4, -(int32_t)(B0 + box[4]));
+    atomicMin(gb + 2, (int32_t)(C0 + box[2])); atomicMin(gb + 5, -(int32_t)(C0 + box[5]));
 }
 
 __device__ __noinline__ void pair_spill_global(PairTable pt, uint32_t* flags, uint32_t lo, uint32_t hi,
-                                               uint32_t axis) {
+                                               uint32_t axis, uint32_t count) {
     atomicAdd(&flags[FLAG_LDS_PAIR_SPILL], 1u);
-    pair_add_global(pt, lo, hi, axis == 0, axis == 1, axis == 2, flags);
+    pair_add_global(pt, lo, hi, axis == 0 ? count : 0, axis == 1 ? count : 0, axis == 2 ? count : 0, flags);
 }
 
 // ---- workgroup-shared LDS tables -----------------------------------------------------------
+struct TileFrame { uint64_t A0, B0, C0; };     // origin of the tile-local frame
+
 template <bool MOM2, typename LDS>
-__device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, uint32_t label,
-                                              const uint64_t (&sv)[NSUM], uint32_t mn0, uint32_t mx0,
-                                              uint32_t mn1, uint32_t mx1, uint32_t mn2, uint32_t mx2) {
-    constexpr int NS = MOM2 ? 10 : 4;
+__device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, const TileFrame& F, uint32_t label,
+                                              const LocalSums& L, uint32_t mna, uint32_t mxa, uint32_t mnb,
+                                              uint32_t mxb, uint32_t mnc, uint32_t mxc) {
+    constexpr int NW = MOM2 ? 6 : 2;
     uint32_t h = hash_u32(label) & (LSLOTS - 1);
     int slot = -1;
 #pragma nounroll
@@ -136,21 +177,39 @@ __device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, uint32
         h = (h + 1) & (LSLOTS - 1);
     }
     if (slot >= 0) {
-        unsigned long long* row = (unsigned long long*)&S.lsum[slot * NS];
-#pragma unroll
-        for (int k = 0; k < NS; ++k) atomicAdd(row + k, (unsigned long long)sv[k]);
-        uint32_t* box = &S.lbox[slot * 6];
-        atomicMin(box + 0, mn0); atomicMax(box + 3, mx0);
-        atomicMin(box + 1, mn1); atomicMax(box + 4, mx1);
-        atomicMin(box + 2, mn2); atomicMax(box + 5, mx2);
+        unsigned long long* row = (unsigned long long*)&S.lsum[slot * NW];
+        atomicAdd(row + 0, (unsigned long long)(L.n | (L.sb << 32)));
+        atomicAdd(row + 1, (unsigned long long)(L.sa | (L.sc << 32)));
+        if (MOM2) {
+            atomicAdd(row + 2, (unsigned long long)(L.saa | (L.sab << 32)));
+            atomicAdd(row + 3, (unsigned long long)(L.sbb | (L.sbc << 32)));
+            atomicAdd(row + (MOM2 ? 4 : 0), (unsigned long long)L.sac);
+            atomicAdd(row + (MOM2 ? 5 : 0), (unsigned long long)L.scc);
+        }
+        // bounding box: read first, touch the atomics only when this contribution extends it
+        uint32_t* box = &S.lbox[slot * 8];
+        const uint4 cur = *reinterpret_cast<const uint4*>(box);          // min a,b,c | max a
+        const uint2 cur2 = *reinterpret_cast<const uint2*>(box + 4);     // max b,c
+        if (mna < cur.x) atomicMin(box + 0, mna);
+        if (mnb < cur.y) atomicMin(box + 1, mnb);
+        if (mnc < cur.z) atomicMin(box + 2, mnc);
+        if (mxa > cur.w) atomicMax(box + 3, mxa);
+        if (mxb > cur2.x) atomicMax(box + 4, mxb);
+        if (mxc > cur2.y) atomicMax(box + 5, mxc);
     } else {                                       // table full: straight to the global rows
-        label_spill_global(A.sums, A.boxes, A.flags, A.max_label, label, sv, NS, mn0, mx0, mn1, mx1, mn2, mx2);
+        // copies made HERE so that only this cold branch (not the hot path) has address-taken locals
+        LocalSums Lc;
+        Lc.n = L.n; Lc.sa = L.sa; Lc.sb = L.sb; Lc.sc = L.sc; Lc.saa = L.saa; Lc.sab = L.sab;
+        Lc.sac = L.sac; Lc.sbb = L.sbb; Lc.sbc = L.sbc; Lc.scc = L.scc;
+        uint32_t bx[6];
+        bx[0] = mna; bx[1] = mnb; bx[2] = mnc; bx[3] = mxa; bx[4] = mxb; bx[5] = mxc;
+        label_spill_global(A.sums, A.boxes, A.flags, A.max_label, label, &Lc, F.A0, F.B0, F.C0, bx);
     }
 }
 
 template <typename LDS>
 __device__ __forceinline__ void lds_pair_add(const SweepArgs& A, LDS& S, uint32_t a, uint32_t b,
-                                             uint32_t axis) {
+                                             uint32_t axis, uint32_t count) {
     const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
     const uint64_t key = ((uint64_t)lo << 32) | hi;
     uint32_t h = hash_pair(lo, hi) & (PSLOTS - 1);
@@ -166,11 +225,8 @@ __device__ __forceinline__ void lds_pair_add(const SweepArgs& A, LDS& S, uint32_
         if (k == key) { slot = (int)h; break; }
         h = (h + 1) & (PSLOTS - 1);
     }
-    if (slot >= 0) {
-        atomicAdd(&S.pcnt[slot * 3 + axis], 1u);
-    } else {
-        pair_spill_global(A.pairs, A.flags, lo, hi, axis);
-    }
+    if (slot >= 0) atomicAdd(&S.pcnt[slot * 3 + axis], count);
+    else pair_spill_global(A.pairs, A.flags, lo, hi, axis, count);
 }
 
 // sum_{x=x0}^{x0+n-1} x  and  x^2  (exact, u64)
@@ -179,16 +235,59 @@ __device__ __forceinline__ uint64_t range_sum2(uint64_t x0, uint64_t n) {
     return n * x0 * x0 + x0 * n * (n - 1) + (n - 1) * n * (2 * n - 1) / 6;
 }
 
+// ---- the consumer ----------------------------------------------------------------------------
+// Drains complete groups of 64 records from both rings of a wave (everything when `all`), every
+// lane busy.  fhead/rhead are advanced; all cursors stay wave-uniform.
+template <bool ADJ, bool MOM2, typename LDS>
+__device__ __forceinline__ void consume_rings(const SweepArgs& A, LDS& S, const TileFrame& F, int w, int lane,
+                                              int& fhead, int ftail, int& rhead, int rtail, bool all) {
+    auto& W = S.wave[w];
+    if (ADJ) {
+        for (;;) {
+            const int cnt = ftail - fhead;
+            if (cnt < 64 && !(all && cnt > 0)) break;
+            const uint2 rec = W.fq[(fhead + lane) & (QCAP - 1)];
+            const bool act = lane < cnt;
+            fhead += cnt < 64 ? cnt : 64;
+            if (TA_ABLATE == 0 && act) {
+                const uint32_t v = rec.x, pv = rec.y & 0x3fffffffu, axis = rec.y >> 30;
+                if (v != INVALID_LABEL && pv < LABEL_LIMIT) lds_pair_add(A, S, pv, v, axis, 1u);
+            }
+        }
+    }
+    for (;;) {
+        const int cnt = rtail - rhead;
+        if (cnt < 64 && !(all && cnt > 0)) break;
+        const uint2 rec = W.rq[(rhead + lane) & (QCAP - 1)];
+        const bool act = lane < cnt;
+        rhead += cnt < 64 ? cnt : 64;
+        if (TA_ABLATE == 0 && act) {
+            const uint32_t label = rec.x, code = rec.y;
+            const uint32_t cl = code & 1023u, bl = (code >> 10) & 15u, a0l = (code >> 14) & 63u, n = code >> 20;
+            if (label != INVALID_LABEL && n != 0u) {
+                const uint32_t a1l = a0l + n - 1u;
+                const uint32_t sa1 = (n * (a0l + a1l)) >> 1;                       // sum a over the run
+                LocalSums L;
+                L.n = n; L.sa = sa1; L.sb = n * bl; L.sc = n * cl;
+                if (MOM2) {
+                    L.saa = n * a0l * a0l + a0l * n * (n - 1u) + ((n - 1u) * n * (2u * n - 1u)) / 6u;
+                    L.sab = bl * sa1; L.sac = sa1 * cl; L.sbb = n * bl * bl; L.sbc = n * bl * cl; L.scc = n * cl * cl;
+                } else {
+                    L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
+                }
+                lds_label_add<MOM2>(A, S, F, label, L, a0l, a1l, bl, bl, cl, cl);
+            }
+        }
+    }
+}
+
 // ---- the wave body ---------------------------------------------------------------------------
 template <typename T, int VPL, int RB, bool ADJ, bool MOM2, typename LDS>
 __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const bool EDGE, const int lane, const int w,
                                            const int64_t c_tile0, const int64_t b_tile0,
                                            const int64_t p_lo, const int64_t p_hi) {
     constexpr int TC = 64 * VPL;
-    constexpr int RS = TC + 4;
-    constexpr int NSLOT = RB * VPL;
-    static_assert(NSLOT == 16, "event bitmaps assume 16 voxels per lane per plane");
-    constexpr int JSH = VPL == 4 ? 2 : 3;                // log2(VPL)
+    static_assert(QCAP >= 128, "rings must hold a leftover (<64) plus one block (<=64)");
     auto& W = S.wave[w];
 
     const T* vol = reinterpret_cast<const T*>(A.vol);
@@ -198,9 +297,13 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const boo
     const bool has_up = ADJ && b_wave0 > 0;
     const bool has_left = ADJ && c_tile0 > 0;
     const bool has_prev = p_lo > 0;
+    TileFrame F;
+    F.A0 = (uint64_t)(A.a_origin + (p_lo - A.first_owned)); F.B0 = (uint64_t)b_tile0; F.C0 = (uint64_t)c_tile0;
+    const uint32_t lane_c = (uint32_t)lane * VPL;
 
-    uint32_t cur[RB][VPL], nxt[RB][VPL], prev[RB][VPL];
-    uint32_t up[VPL], nxt_up[VPL], left[RB], nxt_left[RB];
+    uint32_t cur[RB][VPL], nxt[RB][VPL], nx2[RB][VPL], runlab[RB][VPL];
+    uint32_t a0w[RB][VPL / 4];                 // first plane of each column's open run, one byte per column
+    uint32_t up[VPL], nxt_up[VPL], nx2_up[VPL], left[RB], nxt_left[RB], nx2_left[RB];
 
     auto load_rows = [&](int64_t p, uint32_t (&d)[RB][VPL]) {
         const T* pbase = vol + p * plane;
@@ -228,244 +331,226 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const boo
             load_strip<T, VPL>(EDGE, row, row_ok, c0, n2, dup);
         }
     };
-    auto store_rows = [&](int buf, const uint32_t (&d)[RB][VPL]) {
-        uint32_t* tb = &W.tile[buf][0];
-#pragma unroll
-        for (int r = 0; r < RB; ++r) {
-#pragma unroll
-            for (int q = 0; q < VPL / 4; ++q)
-                *reinterpret_cast<uint4*>(&tb[(r + 1) * RS + 4 + lane * VPL + 4 * q]) =
-                    make_uint4(d[r][4 * q + 0], d[r][4 * q + 1], d[r][4 * q + 2], d[r][4 * q + 3]);
-        }
-    };
-
-    // ---- consumers (64 records per pass, every lane busy) ------------------------------------
-    // faces: code = c_loc | r<<10 | axis<<13 ; voxel in tile[buf], predecessor by address offset
-    auto consume_faces = [&](int count, int buf) {
-        for (int base = 0; base < count; base += 64) {
-            const int i = base + lane;
-            if (i < count) {
-                const uint32_t code = W.fq[i];
-                const uint32_t cl = code & 1023u, r = (code >> 10) & 7u, axis = code >> 13;
-                const int off = (int)((r + 1) * RS + 4 + cl);
-                const uint32_t v = W.tile[buf][off];
-                uint32_t pv;
-                if (axis == 0) pv = W.tile[buf ^ 1][off];
-                else pv = W.tile[buf][axis == 1 ? off - RS : off - 1];
-                if (v != INVALID_LABEL && pv != INVALID_LABEL && v != pv) lds_pair_add(A, S, pv, v, axis);
-            }
-        }
-    };
-    // runs: the column (r, c_loc) closes the run [a0, a1_loc] of the label stored in tile[lbuf]
-    auto consume_runs = [&](int count, int lbuf, uint32_t a1_loc, bool reopen) {
-        for (int base = 0; base < count; base += 64) {
-            const int i = base + lane;
-            if (i < count) {
-                const uint32_t code = W.rq[i];
-                const uint32_t cl = code & 1023u, r = (code >> 10) & 7u;
-                const uint32_t label = W.tile[lbuf][(r + 1) * RS + 4 + cl];
-                const uint32_t a0l = W.a0[r * TC + cl];
-                if (reopen) W.a0[r * TC + cl] = (uint8_t)(a1_loc + 1u);
-                if (label != INVALID_LABEL) {
-                    const uint64_t gc = (uint64_t)(c_tile0 + (int64_t)cl);
-                    const uint64_t gb = (uint64_t)(b_wave0 + (int64_t)r);
-                    const uint64_t ga0 = (uint64_t)(A.a_origin + (p_lo + a0l - A.first_owned));
-                    const uint32_t n = a1_loc - a0l + 1u;
-                    uint64_t sv[NSUM];
-                    run_moments<MOM2>(ga0, n, gb, gc, sv);
-                    lds_label_add<MOM2>(A, S, label, sv, (uint32_t)ga0, (uint32_t)(ga0 + n - 1),
-                                        (uint32_t)gb, (uint32_t)gb, (uint32_t)gc, (uint32_t)gc);
-                }
-            }
-        }
-    };
 
     // ---- prologue ------------------------------------------------------------------------------
-    if (has_prev) {
-        load_rows(p_lo - 1, prev);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) { up[j] = INVALID_LABEL; nxt_up[j] = INVALID_LABEL; nx2_up[j] = INVALID_LABEL; }
+#pragma unroll
+    for (int r = 0; r < RB; ++r) { left[r] = INVALID_LABEL; nxt_left[r] = INVALID_LABEL; nx2_left[r] = INVALID_LABEL; }
+    load_rows(p_lo, cur);
+    load_halo(p_lo, up, left);
+    if (ADJ && has_prev) {
+        load_rows(p_lo - 1, runlab);       // the plane before the tile: faces only (its runs have length 0)
     } else {
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) prev[r][j] = INVALID_LABEL;
+            for (int j = 0; j < VPL; ++j) runlab[r][j] = cur[r][j];
     }
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) { up[j] = INVALID_LABEL; nxt_up[j] = INVALID_LABEL; }
-#pragma unroll
-    for (int r = 0; r < RB; ++r) { left[r] = INVALID_LABEL; nxt_left[r] = INVALID_LABEL; }
-    load_rows(p_lo, cur);
-    load_halo(p_lo, up, left);
     if (p_lo + 1 < p_hi) { load_rows(p_lo + 1, nxt); load_halo(p_lo + 1, nxt_up, nxt_left); }
+    if (TA_PREFETCH >= 2 && p_lo + 2 < p_hi) { load_rows(p_lo + 2, nx2); load_halo(p_lo + 2, nx2_up, nx2_left); }
 #pragma unroll
     for (int r = 0; r < RB; ++r)
 #pragma unroll
-        for (int q = 0; q < VPL / 4; ++q)
-            *reinterpret_cast<uint32_t*>(&W.a0[r * TC + lane * VPL + 4 * q]) = 0u;
+        for (int q = 0; q < VPL / 4; ++q) a0w[r][q] = 0u;
 
-    int buf = 0;                 // LDS plane buffer that receives the current plane
-    bool prev_in_lds = false;    // tile[buf ^ 1] holds `prev`
-    bool any_event = false;      // this wave tile has seen at least one event
+    int fhead = 0, ftail = 0, rhead = 0, rtail = 0;       // free-running ring cursors (wave-uniform)
+    bool any_event = false;
+#ifdef TA_STAMPS
+    uint64_t tk_cmp = 0, tk_emit = 0, tk_cons = 0, tk_adv = 0, tk_rows = 0, tk_evrows = 0;
+    const uint64_t tk_begin = __builtin_amdgcn_s_memtime();
+#define TA_T() __builtin_amdgcn_s_memtime()
+#endif
     const uint32_t first_label = __builtin_amdgcn_readfirstlane(cur[0][0]);
+    const uint32_t last = (uint32_t)(p_hi - 1 - p_lo);
 
     for (int64_t p = p_lo; p < p_hi; ++p) {
-        const bool first = p == p_lo;
         const uint32_t ploc = (uint32_t)(p - p_lo);
-
-        // ---- 1. event bitmaps, registers only
-        uint32_t e0 = 0, e1 = 0;         // e0: axis-1 bits [0,16) | axis-2 bits [16,32) ; e1: axis-0 bits
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
+            // ---- 1. the row's 3*VPL compares, batched: masks land in SGPRs, no branch yet
+#ifdef TA_STAMPS
+            const uint64_t t0 = TA_T();
+#endif
+            uint64_t mb[VPL], mc[VPL], ma[VPL];
+            uint32_t pcv[VPL];
+            int nface = 0, nrun = 0;
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
-                const int s = r * VPL + j;
                 const uint32_t v = cur[r][j];
                 if (ADJ) {
-                    if (r > 0) e0 |= (uint32_t)(v != cur[r > 0 ? r - 1 : 0][j]) << s;
-                    else if (has_up) e0 |= (uint32_t)(v != up[j]) << s;
-                    uint32_t pc;
-                    if (j == 0) pc = lane_shr1(cur[r][VPL - 1], has_left ? left[r] : cur[r][0]);
-                    else pc = cur[r][j > 0 ? j - 1 : 0];
-                    e0 |= (uint32_t)(v != pc) << (16 + s);
+                    if (r > 0) mb[j] = __builtin_amdgcn_ballot_w64(v != cur[r > 0 ? r - 1 : 0][j]);
+                    else mb[j] = has_up ? __builtin_amdgcn_ballot_w64(v != up[j]) : 0ull;
+                    pcv[j] = j > 0 ? cur[r][j > 0 ? j - 1 : 0]
+                                   : lane_shr1(cur[r][VPL - 1], has_left ? left[r] : cur[r][0]);
+                    mc[j] = __builtin_amdgcn_ballot_w64(v != pcv[j]);
+                    nface += __popcll(mb[j]) + __popcll(mc[j]);
+                } else {
+                    mb[j] = 0ull; mc[j] = 0ull; pcv[j] = 0u;
                 }
-                e1 |= (uint32_t)(v != prev[r][j]) << s;
+                ma[j] = __builtin_amdgcn_ballot_w64(v != runlab[r][j]);
+                nrun += __popcll(ma[j]);
             }
-        }
-        if (first && !(ADJ && has_prev)) e1 = 0;     // nothing before the tile: no face, no run
-
-        // ---- 2. nobody saw anything: the step is over
-        const uint32_t nev = (uint32_t)__popc(e0) + (uint32_t)__popc(e1);
-        const uint32_t nrun = first ? 0u : (uint32_t)__popc(e1);
-        if (__builtin_amdgcn_ballot_w64(nev != 0) != 0) {
+            if (ADJ) nface += nrun;
+#ifdef TA_STAMPS
+            const uint64_t t1 = TA_T();
+            tk_cmp += t1 - t0; tk_rows += 1;
+#endif
+            if (nface + nrun == 0) continue;              // the common case: one branch per row
             any_event = true;
-            // ---- 3. stage the plane in LDS, scan the counts, emit position codes
-            store_rows(buf, cur);
-            if (ADJ) {
-                if (has_up) {
+            // ---- 2. emit + 3. consume.  Firing lanes append value-carrying records at mask-prefix
+            // offsets; the block list is straight-line and predicated.  Normally the whole row is one
+            // pass.  A row whose records might not fit in the rings (never seen on tissue, only on
+            // noise) runs one block per pass, each followed by the same single consumer site.
+            const bool overflow = (ftail - fhead) + nface > QCAP || (rtail - rhead) + nrun > QCAP;
+            const int npass = overflow ? 3 * VPL : 1;
+#pragma nounroll
+            for (int pass = 0; pass < npass; ++pass) {
+                int fo = ftail, ro = rtail;
 #pragma unroll
-                    for (int q = 0; q < VPL / 4; ++q)
-                        *reinterpret_cast<uint4*>(&W.tile[buf][4 + lane * VPL + 4 * q]) =
-                            make_uint4(up[4 * q + 0], up[4 * q + 1], up[4 * q + 2], up[4 * q + 3]);
-                }
-                if (has_left && lane == 0) {
-#pragma unroll
-                    for (int r = 0; r < RB; ++r) W.tile[buf][(r + 1) * RS + 3] = left[r];
-                }
-            }
-            if (!prev_in_lds) store_rows(buf ^ 1, prev);
-
-            const uint32_t packed = nev | (nrun << 16);
-            const uint32_t incl = wave_scan_add(packed);
-            const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            const int tot_ev = (int)(total & 0xffffu);
-            int fidx = (int)((incl - packed) & 0xffffu);     // index of this lane's next event
-            int ridx = (int)((incl - packed) >> 16);         // index of this lane's next run record
-            int rbase = 0;                                   // run records emitted in earlier windows
-            for (int win = 0; win < tot_ev; win += QCAP) {
-                int nrun_win = 0;
-                for (;;) {
-                    const bool can = ((e0 | e1) != 0u) && (fidx < win + QCAP);
-                    const uint64_t m = __builtin_amdgcn_ballot_w64(can);
-                    if (m == 0) break;
-                    bool isrun = false;
-                    if (can) {
-                        const bool isa = e0 == 0u;
-                        const uint32_t bits = isa ? e1 : e0;
-                        const uint32_t k = (uint32_t)__builtin_ctz(bits);
-                        if (isa) e1 = bits & (bits - 1u); else e0 = bits & (bits - 1u);
-                        const uint32_t s = k & 15u;
-                        const uint32_t axis = isa ? 0u : 1u + (k >> 4);
-                        const uint32_t code = ((uint32_t)lane * VPL + (s & (VPL - 1))) | ((s >> JSH) << 10);
-                        if (ADJ) W.fq[fidx - win] = code | (axis << 13);
-                        ++fidx;
-                        isrun = isa && !first;
-                        if (isrun) { W.rq[ridx - rbase] = code; ++ridx; }
+                for (int j = 0; j < VPL; ++j) {
+                    const uint32_t v = cur[r][j];
+                    if (ADJ) {
+                        if ((r > 0 || has_up) && (!overflow || pass == 3 * j)) {
+                            const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];
+                            if (v != pv) W.fq[(fo + (int)mbcnt64(mb[j])) & (QCAP - 1)] = make_uint2(v, pv | (1u << 30));
+                            fo += __popcll(mb[j]);
+                        }
+                        if (!overflow || pass == 3 * j + 1) {
+                            if (v != pcv[j]) W.fq[(fo + (int)mbcnt64(mc[j])) & (QCAP - 1)] = make_uint2(v, pcv[j] | (2u << 30));
+                            fo += __popcll(mc[j]);
+                        }
                     }
-                    nrun_win += __popcll(__builtin_amdgcn_ballot_w64(isrun));
+                    if (!overflow || pass == 3 * j + 2) {
+                        // axis 0: closes the column's open run (length ploc - a0; 0 for the plane before the tile)
+                        const uint32_t o = runlab[r][j];
+                        const uint32_t i = mbcnt64(ma[j]);
+                        const uint32_t sh = 8u * (j % 4);
+                        const uint32_t a0 = (a0w[r][j / 4] >> sh) & 0xffu;
+                        if (v != o) {
+                            if (ADJ) W.fq[(fo + (int)i) & (QCAP - 1)] = make_uint2(v, o);
+                            W.rq[(ro + (int)i) & (QCAP - 1)] =
+                                make_uint2(o, (lane_c + j) | ((uint32_t)(w * RB + r) << 10) | (a0 << 14) | ((ploc - a0) << 20));
+                            a0w[r][j / 4] = (a0w[r][j / 4] & ~(0xffu << sh)) | (ploc << sh);
+                            runlab[r][j] = v;
+                        }
+                        const int n = __popcll(ma[j]);
+                        if (ADJ) fo += n;
+                        ro += n;
+                    }
                 }
-                __builtin_amdgcn_wave_barrier();
-                // ---- 4. dense consumers
-                const int nface_win = tot_ev - win < QCAP ? tot_ev - win : QCAP;
-                if (ADJ) consume_faces(nface_win, buf);
-                if (nrun_win) consume_runs(nrun_win, buf ^ 1, ploc - 1u, true);
-                rbase += nrun_win;
-                __builtin_amdgcn_wave_barrier();
+                ftail = fo; rtail = ro;
+#ifdef TA_STAMPS
+                const uint64_t t2 = TA_T();
+                if (pass == 0) { tk_emit += t2 - t1; tk_evrows += 1; }
+#endif
+                if (ftail - fhead >= 64 || rtail - rhead >= 64) {
+                    __builtin_amdgcn_wave_barrier();
+                    consume_rings<ADJ, MOM2, LDS>(A, S, F, w, lane, fhead, ftail, rhead, rtail, false);
+                    __builtin_amdgcn_wave_barrier();
+                }
+#ifdef TA_STAMPS
+                tk_cons += TA_T() - t2;
+#endif
             }
-            prev_in_lds = true;
-            buf ^= 1;
-        } else {
-            prev_in_lds = false;
         }
-
-        // ---- advance: current plane becomes the previous one, prefetched plane becomes current
-#pragma unroll
-        for (int r = 0; r < RB; ++r)
-#pragma unroll
-            for (int j = 0; j < VPL; ++j) prev[r][j] = cur[r][j];
+#ifdef TA_STAMPS
+        const uint64_t t4 = TA_T();
+#endif
+        // ---- advance: rotate the register planes, keep TA_PREFETCH planes of loads in flight
         if (p + 1 < p_hi) {
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
 #pragma unroll
-                for (int j = 0; j < VPL; ++j) cur[r][j] = nxt[r][j];
+                for (int j = 0; j < VPL; ++j) {
+                    cur[r][j] = nxt[r][j];
+                    if (TA_PREFETCH >= 2) nxt[r][j] = nx2[r][j];
+                }
                 left[r] = nxt_left[r];
+                if (TA_PREFETCH >= 2) nxt_left[r] = nx2_left[r];
             }
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) up[j] = nxt_up[j];
-            if (p + 2 < p_hi) { load_rows(p + 2, nxt); load_halo(p + 2, nxt_up, nxt_left); }
+            for (int j = 0; j < VPL; ++j) {
+                up[j] = nxt_up[j];
+                if (TA_PREFETCH >= 2) nxt_up[j] = nx2_up[j];
+            }
+            if (TA_PREFETCH >= 2) {
+                if (p + 3 < p_hi) { load_rows(p + 3, nx2); load_halo(p + 3, nx2_up, nx2_left); }
+            } else {
+                if (p + 2 < p_hi) { load_rows(p + 2, nxt); load_halo(p + 2, nxt_up, nxt_left); }
+            }
         }
+#ifdef TA_STAMPS
+        {   // make the wait for the rotated registers visible here, not in the next compare
+            uint32_t sink = cur[0][0];
+            asm volatile("" :: "v"(sink));
+            tk_adv += TA_T() - t4;
+        }
+#endif
     }
+#ifdef TA_STAMPS
+    if (lane == 0) {
+        atomicAdd(&A.flags[8], (uint32_t)(tk_cmp >> 8)); atomicAdd(&A.flags[9], (uint32_t)(tk_emit >> 8));
+        atomicAdd(&A.flags[10], (uint32_t)(tk_cons >> 8)); atomicAdd(&A.flags[11], (uint32_t)(tk_adv >> 8));
+        atomicAdd(&A.flags[12], (uint32_t)((TA_T() - tk_begin) >> 8));
+        atomicAdd(&A.flags[13], (uint32_t)tk_rows); atomicAdd(&A.flags[14], (uint32_t)tk_evrows);
+    }
+#endif
 
     // ---- end of tile: close every open run --------------------------------------------------
-    const uint32_t last = (uint32_t)(p_hi - 1 - p_lo);
     if (ADJ && !any_event) {
-        // no event at all (needs the in-plane compares of ADJ): the whole wave tile is one label (or lies outside the volume): closed-form box
+        // no event at all (needs the in-plane compares of ADJ): the whole wave tile is one label
+        // (or lies outside the volume): one closed-form box in tile-local coordinates
         if (lane == 0 && first_label != INVALID_LABEL) {
-            const uint64_t na = last + 1u, nb = RB, nc = TC;
-            const uint64_t ga = (uint64_t)(A.a_origin + (p_lo - A.first_owned)), gb = (uint64_t)b_wave0,
-                           gc = (uint64_t)c_tile0;
-            const uint64_t sa = range_sum1(ga, na), sb = range_sum1(gb, nb), sc = range_sum1(gc, nc);
-            uint64_t sv[NSUM];
-            sv[0] = na * nb * nc; sv[1] = sa * nb * nc; sv[2] = sb * na * nc; sv[3] = sc * na * nb;
+            const uint64_t na = last + 1u, nb = RB, nc = TC, b0 = (uint64_t)w * RB;
+            const uint64_t sa = range_sum1(0, na), sb = range_sum1(b0, nb), sc = range_sum1(0, nc);
+            LocalSums L;
+            L.n = na * nb * nc; L.sa = sa * nb * nc; L.sb = sb * na * nc; L.sc = sc * na * nb;
             if (MOM2) {
-                sv[4] = range_sum2(ga, na) * nb * nc; sv[5] = sa * sb * nc; sv[6] = sa * sc * nb;
-                sv[7] = range_sum2(gb, nb) * na * nc; sv[8] = sb * sc * na; sv[9] = range_sum2(gc, nc) * na * nb;
+                L.saa = range_sum2(0, na) * nb * nc; L.sab = sa * sb * nc; L.sac = sa * sc * nb;
+                L.sbb = range_sum2(b0, nb) * na * nc; L.sbc = sb * sc * na; L.scc = range_sum2(0, nc) * na * nb;
             } else {
-                sv[4] = sv[5] = sv[6] = sv[7] = sv[8] = sv[9] = 0;
+                L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
             }
-            lds_label_add<MOM2>(A, S, first_label, sv, (uint32_t)ga, (uint32_t)(ga + na - 1), (uint32_t)gb,
-                                (uint32_t)(gb + nb - 1), (uint32_t)gc, (uint32_t)(gc + nc - 1));
+            lds_label_add<MOM2>(A, S, F, first_label, L, 0u, last, (uint32_t)b0, (uint32_t)(b0 + nb - 1), 0u,
+                                (uint32_t)(nc - 1));
         }
     } else {
-        // `prev` holds the last plane; make sure LDS does too, then run every column through
-        // the run consumer (QCAP codes per window)
-        const int lbuf = buf ^ 1;
-        if (!prev_in_lds) store_rows(lbuf, prev);
-#pragma nounroll
-        for (int rq = 0; rq < RB * (VPL / 4); ++rq) {      // runtime loop: one consumer site
-            const uint32_t r = (uint32_t)rq / (VPL / 4), q = (uint32_t)rq % (VPL / 4);
-            __builtin_amdgcn_wave_barrier();
+        // every column closes its run [a0, last]: RB*VPL dense blocks of 64 records, consumed as they come
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                W.rq[j * 64 + lane] = ((uint32_t)lane * VPL + 4 * q + j) | (r << 10);
-            __builtin_amdgcn_wave_barrier();
-            consume_runs(QCAP, lbuf, last, false);
+        for (int r = 0; r < RB; ++r) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const uint32_t a0 = (a0w[r][j / 4] >> (8u * (j % 4))) & 0xffu;
+                W.rq[(rtail + lane) & (QCAP - 1)] =
+                    make_uint2(runlab[r][j], (lane_c + j) | ((uint32_t)(w * RB + r) << 10) | (a0 << 14) | ((last + 1u - a0) << 20));
+                rtail += 64;
+                if (QCAP < 64 * (VPL + 1) || j == VPL - 1) {
+                    __builtin_amdgcn_wave_barrier();
+                    consume_rings<ADJ, MOM2, LDS>(A, S, F, w, lane, fhead, ftail, rhead, rtail, r == RB - 1 && j == VPL - 1);
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
         }
     }
 }
 
 template <typename T, int VPL, int RB, bool ADJ, bool MOM2>
-__global__ void __launch_bounds__(WAVES * 64) sweep_kernel(SweepArgs A) {
-    constexpr int NS = MOM2 ? 10 : 4;
+__global__ void __launch_bounds__(WAVES * 64, TA_MINWAVES) sweep_kernel(SweepArgs A) {
+    constexpr int NW = MOM2 ? 6 : 2;
     constexpr int TC = 64 * VPL, TB = WAVES * RB;
-    using LDS = SweepLds<NS, RB, TC>;
+    static_assert(TB <= 16 && TC <= 512, "packed LDS moment words assume <= 16 rows x 512 columns per tile");
+    using LDS = SweepLds<NW>;
     __shared__ LDS S;
 
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave index: make it provably wave-uniform
     for (int i = tid; i < LSLOTS; i += WAVES * 64) {
         S.lkeys[i] = INVALID_LABEL;
 #pragma unroll
-        for (int k = 0; k < NS; ++k) S.lsum[i * NS + k] = 0ull;
-        S.lbox[i * 6 + 0] = 0xFFFFFFFFu; S.lbox[i * 6 + 1] = 0xFFFFFFFFu; S.lbox[i * 6 + 2] = 0xFFFFFFFFu;
-        S.lbox[i * 6 + 3] = 0u; S.lbox[i * 6 + 4] = 0u; S.lbox[i * 6 + 5] = 0u;
+        for (int k = 0; k < NW; ++k) S.lsum[i * NW + k] = 0ull;
+        S.lbox[i * 8 + 0] = 0xFFFFFFFFu; S.lbox[i * 8 + 1] = 0xFFFFFFFFu; S.lbox[i * 8 + 2] = 0xFFFFFFFFu;
+        S.lbox[i * 8 + 3] = 0u; S.lbox[i * 8 + 4] = 0u; S.lbox[i * 8 + 5] = 0u;
     }
     if (ADJ) {
         for (int i = tid; i < PSLOTS; i += WAVES * 64) {
@@ -491,20 +576,32 @@ __global__ void __launch_bounds__(WAVES * 64) sweep_kernel(SweepArgs A) {
     }
     __syncthreads();
 
-    // ---- flush the workgroup tables with global atomics
+    // ---- flush the workgroup tables with global atomics (local -> global coordinates here)
+    const uint64_t A0 = (uint64_t)(A.a_origin + (p_lo - A.first_owned)), B0 = (uint64_t)b_tile0, C0 = (uint64_t)c_tile0;
     for (int i = tid; i < LSLOTS; i += WAVES * 64) {
         const uint32_t label = S.lkeys[i];
         if (label == INVALID_LABEL) continue;
         if (label > A.max_label) { atomicOr(&A.flags[FLAG_RANGE], 1u); continue; }
+        const uint64_t w0 = S.lsum[i * NW + 0], w1 = S.lsum[i * NW + 1];
+        LocalSums L;
+        L.n = w0 & 0xffffffffull; L.sb = w0 >> 32; L.sa = w1 & 0xffffffffull; L.sc = w1 >> 32;
+        if (MOM2) {
+            const uint64_t w2 = S.lsum[i * NW + (MOM2 ? 2 : 0)], w3 = S.lsum[i * NW + (MOM2 ? 3 : 0)];
+            L.saa = w2 & 0xffffffffull; L.sab = w2 >> 32;
+            L.sbb = w3 & 0xffffffffull; L.sbc = w3 >> 32;
+            L.sac = S.lsum[i * NW + (MOM2 ? 4 : 0)]; L.scc = S.lsum[i * NW + (MOM2 ? 5 : 0)];
+        } else {
+            L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
+        }
+        uint64_t g[NSUM];
+        local_to_global(L, A0, B0, C0, g);
         unsigned long long* row = (unsigned long long*)&A.sums[(uint64_t)label * NSUM];
 #pragma unroll
-        for (int k = 0; k < NS; ++k) atomicAdd(row + k, (unsigned long long)S.lsum[i * NS + k]);
+        for (int k = 0; k < (MOM2 ? NSUM : 4); ++k) atomicAdd(row + k, (unsigned long long)g[k]);
         int32_t* box = &A.boxes[(uint64_t)label * NBOX];
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            atomicMin(box + d, (int32_t)S.lbox[i * 6 + d]);
-            atomicMin(box + 3 + d, -(int32_t)S.lbox[i * 6 + 3 + d]);
-        }
+        atomicMin(box + 0, (int32_t)(A0 + S.lbox[i * 8 + 0])); atomicMin(box + 3, -(int32_t)(A0 + S.lbox[i * 8 + 3]));
+        atomicMin(box + 1, (int32_t)(B0 + S.lbox[i * 8 + 1])); atomicMin(box + 4, -(int32_t)(B0 + S.lbox[i * 8 + 4]));
+        atomicMin(box + 2, (int32_t)(C0 + S.lbox[i * 8 + 2])); atomicMin(box + 5, -(int32_t)(C0 + S.lbox[i * 8 + 5]));
     }
     if (ADJ) {
         for (int i = tid; i < PSLOTS; i += WAVES * 64) {
@@ -517,6 +614,7 @@ __global__ void __launch_bounds__(WAVES * 64) sweep_kernel(SweepArgs A) {
 }
 
 int sweep_default_tile_planes() { return 32; }   // 64 planes start to overflow the 128-slot label table
+int sweep_max_tile_planes() { return MAX_TILE_PLANES; }
 
 template <typename T, int VPL, int RB>
 static void launch_sweep_t(hipStream_t s, const SweepArgs& a, uint32_t fm) {
@@ -535,7 +633,7 @@ static void launch_sweep_t(hipStream_t s, const SweepArgs& a, uint32_t fm) {
 
 void launch_sweep(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask) {
     if (itemsize == 2) launch_sweep_t<uint16_t, 8, 2>(s, a, feature_mask);
-    else               launch_sweep_t<uint32_t, 4, 4>(s, a, feature_mask);
+    else               launch_sweep_t<uint32_t, 4, TA_RB32>(s, a, feature_mask);
 }
 
 }  // namespace ta

@@ -142,7 +142,7 @@ int run_extract(ta_ctx* c) {
     a.a_origin = c->a_origin;
     a.first_owned = c->first_owned;
     a.tile_planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes();
-    if (a.tile_planes > 255) a.tile_planes = 255;   // run starts are kept as u8 in LDS
+    if (a.tile_planes > ta::sweep_max_tile_planes()) a.tile_planes = ta::sweep_max_tile_planes();   // packed LDS moment words
     a.vec_ok = (((uintptr_t)c->vol & 15) == 0) && ((a.n2 * c->itemsize) % 16 == 0);
     a.max_label = c->max_label;
     a.sums = c->sums;
@@ -270,7 +270,7 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
             if (value != 0 && value != 1) return fail(TA_EINVAL, "TA_OPT_IMPL must be 0 or 1");
             c->impl = (int)value; return TA_OK;
         case TA_OPT_TILE_PLANES:
-            if (value < 0 || value > 255) return fail(TA_EINVAL, "TA_OPT_TILE_PLANES must be in [0,255]");
+            if (value < 0 || value > ta::sweep_max_tile_planes()) return fail(TA_EINVAL, "TA_OPT_TILE_PLANES must be in [0,%d]", ta::sweep_max_tile_planes());
             c->tile_planes = (int)value; return TA_OK;
         case TA_OPT_PAIR_SLOTS:
             if (value != 0 && (value < 4 || value > 30)) return fail(TA_EINVAL, "TA_OPT_PAIR_SLOTS must be 0 or in [4,30]");
@@ -502,13 +502,13 @@ TA_API int ta_timing(ta_ctx* c, double* ms_sweep, double* ms_adjacency, double* 
     return TA_OK;
 }
 
-TA_API int ta_debug_counters(ta_ctx* c, uint32_t out[8]) {
+TA_API int ta_debug_counters(ta_ctx* c, uint32_t out[16]) {
     if (!c || !out) return fail(TA_EINVAL, "NULL argument");
     if (!c->extracted) return fail(TA_EINVAL, "no extraction has been run on this context");
     int rc = use_device(c);
     if (rc != TA_OK) return rc;
     TA_HIP(hipStreamSynchronize(c->stream));
-    for (int i = 0; i < 8; ++i) out[i] = i < ta::NFLAGS ? c->h_small[i] : 0u;
+    for (int i = 0; i < 16; ++i) out[i] = i < ta::NFLAGS ? c->h_small[i] : 0u;
     return TA_OK;
 }
 

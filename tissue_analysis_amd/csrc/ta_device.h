@@ -14,7 +14,7 @@ constexpr int NSUM = 10;                            // count, s0,s1,s2, s00,s01,
 constexpr int NBOX = 6;                             // min0,min1,min2,-max0,-max1,-max2
 
 // flag words written by kernels, read back by the host after the stream drains
-enum { FLAG_RANGE = 0, FLAG_PAIR_OVERFLOW = 1, FLAG_LDS_LABEL_SPILL = 2, FLAG_LDS_PAIR_SPILL = 3, NFLAGS = 8 };
+enum { FLAG_RANGE = 0, FLAG_PAIR_OVERFLOW = 1, FLAG_LDS_LABEL_SPILL = 2, FLAG_LDS_PAIR_SPILL = 3, NFLAGS = 16 };
 
 struct PairTable {           // device-global open-addressing hash: key = lo<<32|hi
     uint64_t* keys;          // [cap], EMPTY_KEY when free

@@ -21,5 +21,6 @@ void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3],
 // kernels_sweep.hip
 void launch_sweep(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);
 int sweep_default_tile_planes();
+int sweep_max_tile_planes();
 
 }  // namespace ta
