@@ -50,7 +50,7 @@ def weak_config(n_gpus):
     return dict(name="C4x%d" % n_gpus, dims=dims, dtype="uint32", n_cells=n_cells, seed=2)
 
 
-def cpu_baseline(vol_tensor, dims, dtype, edge=256):
+def cpu_baseline(vol_tensor, dims, dtype, edge=400):
     """Time the oracle (reference algorithm restated, 1 core) on a centred crop of the volume."""
     from oracle.sia_oracle import full_feature_set
     from tissue_analysis_amd import synth
