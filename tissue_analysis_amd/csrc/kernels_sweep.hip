@@ -99,11 +99,13 @@ __device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
 }
 
 // ---- strip loads ---------------------------------------------------------------------------
+// `row_c0` points at the wave's first voxel of the row (wave-uniform, lives in SGPRs); lanes add a
+// 32-bit byte offset, so the 16-byte loads use the saddr + voffset form and no 64-bit VGPR address.
 template <typename T, int VPL>
-__device__ __forceinline__ void load_strip(const bool EDGE, const T* row, bool row_ok, int64_t c, int64_t n2,
-                                           uint32_t (&dst)[VPL]) {
+__device__ __forceinline__ void load_strip(const bool EDGE, const T* row_c0, bool row_ok, uint32_t lane_off,
+                                           int64_t c, int64_t n2, uint32_t (&dst)[VPL]) {
     if (!EDGE) {
-        const uint4 x = *reinterpret_cast<const uint4*>(row + c);
+        const uint4 x = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(row_c0) + lane_off);
         if (sizeof(T) == 4) {
             dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
         } else {
@@ -112,14 +114,27 @@ __device__ __forceinline__ void load_strip(const bool EDGE, const T* row, bool r
             dst[6 % VPL] = x.w & 0xffffu; dst[7 % VPL] = x.w >> 16;
         }
     } else {
+        const T* lane_p = reinterpret_cast<const T*>(reinterpret_cast<const char*>(row_c0) + lane_off);
 #pragma unroll
         for (int j = 0; j < VPL; ++j)
-            dst[j] = (row_ok && c + j < n2) ? (uint32_t)row[c + j] : INVALID_LABEL;
+            dst[j] = (row_ok && c + j < n2) ? (uint32_t)lane_p[j] : INVALID_LABEL;
     }
+}
+
+// one voxel at a wave-uniform address through the scalar cache (SMEM): no VGPR, no vector-memory slot
+template <typename T>
+__device__ __forceinline__ uint32_t load_uniform_voxel(const T* p) {
+    typedef const __attribute__((address_space(4))) uint32_t* cptr;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t word = *reinterpret_cast<cptr>(a & ~(uintptr_t)3);
+    if (sizeof(T) == 4) return word;
+    return (a & 2) ? (word >> 16) : (word & 0xffffu);
 }
 
 // local sums of one label contribution (tile-local coordinates)
 struct LocalSums { uint64_t n, sa, sb, sc, saa, sab, sac, sbb, sbc, scc; };
+// one run's contribution: every term fits 32 bits (n <= 64, a < 64, b < 16, c < 512)
+struct RunSums { uint32_t n, sa, sb, sc, saa, sab, sac, sbb, sbc, scc; };
 
 // shift tile-local sums to global coordinates (origin A0,B0,C0): exact u64
 __device__ __forceinline__ void local_to_global(const LocalSums& L, uint64_t A0, uint64_t B0, uint64_t C0,
@@ -159,9 +174,9 @@ __device__ __noinline__ void pair_spill_global(PairTable pt, uint32_t* flags, ui
 // ---- workgroup-shared LDS tables -----------------------------------------------------------
 struct TileFrame { uint64_t A0, B0, C0; };     // origin of the tile-local frame
 
-template <bool MOM2, typename LDS>
+template <bool MOM2, typename LDS, typename SUMS>
 __device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, const TileFrame& F, uint32_t label,
-                                              const LocalSums& L, uint32_t mna, uint32_t mxa, uint32_t mnb,
+                                              const SUMS& L, uint32_t mna, uint32_t mxa, uint32_t mnb,
                                               uint32_t mxb, uint32_t mnc, uint32_t mxc) {
     constexpr int NW = MOM2 ? 6 : 2;
     uint32_t h = hash_u32(label) & (LSLOTS - 1);
@@ -178,11 +193,11 @@ __device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, const 
     }
     if (slot >= 0) {
         unsigned long long* row = (unsigned long long*)&S.lsum[slot * NW];
-        atomicAdd(row + 0, (unsigned long long)(L.n | (L.sb << 32)));
-        atomicAdd(row + 1, (unsigned long long)(L.sa | (L.sc << 32)));
+        atomicAdd(row + 0, (unsigned long long)((uint64_t)L.n | ((uint64_t)L.sb << 32)));
+        atomicAdd(row + 1, (unsigned long long)((uint64_t)L.sa | ((uint64_t)L.sc << 32)));
         if (MOM2) {
-            atomicAdd(row + 2, (unsigned long long)(L.saa | (L.sab << 32)));
-            atomicAdd(row + 3, (unsigned long long)(L.sbb | (L.sbc << 32)));
+            atomicAdd(row + 2, (unsigned long long)((uint64_t)L.saa | ((uint64_t)L.sab << 32)));
+            atomicAdd(row + 3, (unsigned long long)((uint64_t)L.sbb | ((uint64_t)L.sbc << 32)));
             atomicAdd(row + (MOM2 ? 4 : 0), (unsigned long long)L.sac);
             atomicAdd(row + (MOM2 ? 5 : 0), (unsigned long long)L.scc);
         }
@@ -267,7 +282,7 @@ __device__ __forceinline__ void consume_rings(const SweepArgs& A, LDS& S, const 
             if (label != INVALID_LABEL && n != 0u) {
                 const uint32_t a1l = a0l + n - 1u;
                 const uint32_t sa1 = (n * (a0l + a1l)) >> 1;                       // sum a over the run
-                LocalSums L;
+                RunSums L;
                 L.n = n; L.sa = sa1; L.sb = n * bl; L.sc = n * cl;
                 if (MOM2) {
                     L.saa = n * a0l * a0l + a0l * n * (n - 1u) + ((n - 1u) * n * (2u * n - 1u)) / 6u;
@@ -275,7 +290,7 @@ __device__ __forceinline__ void consume_rings(const SweepArgs& A, LDS& S, const 
                 } else {
                     L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
                 }
-                lds_label_add<MOM2>(A, S, F, label, L, a0l, a1l, bl, bl, cl, cl);
+                lds_label_add<MOM2, LDS, RunSums>(A, S, F, label, L, a0l, a1l, bl, bl, cl, cl);
             }
         }
     }
@@ -300,6 +315,7 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const boo
     TileFrame F;
     F.A0 = (uint64_t)(A.a_origin + (p_lo - A.first_owned)); F.B0 = (uint64_t)b_tile0; F.C0 = (uint64_t)c_tile0;
     const uint32_t lane_c = (uint32_t)lane * VPL;
+    const uint32_t lane_off = lane_c * (uint32_t)sizeof(T);
 
     uint32_t cur[RB][VPL], nxt[RB][VPL], nx2[RB][VPL], runlab[RB][VPL];
     uint32_t a0w[RB][VPL / 4];                 // first plane of each column's open run, one byte per column
@@ -311,8 +327,8 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const boo
         for (int r = 0; r < RB; ++r) {
             const int64_t b = b_wave0 + r;
             const bool row_ok = b < n1;
-            const T* row = pbase + (EDGE ? (row_ok ? b : 0) : b) * n2;
-            load_strip<T, VPL>(EDGE, row, row_ok, c0, n2, d[r]);
+            const T* row = pbase + (EDGE ? (row_ok ? b : 0) : b) * n2 + c_tile0;
+            load_strip<T, VPL>(EDGE, row, row_ok, lane_off, c0, n2, d[r]);
         }
     };
     auto load_halo = [&](int64_t p, uint32_t (&dup)[VPL], uint32_t (&dl)[RB]) {
@@ -321,14 +337,13 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const boo
 #pragma unroll
             for (int r = 0; r < RB; ++r) {
                 const int64_t b = b_wave0 + r;
-                dl[r] = INVALID_LABEL;
-                if (lane == 0 && b < n1) dl[r] = (uint32_t)pbase[b * n2 + c_tile0 - 1];
+                dl[r] = b < n1 ? load_uniform_voxel<T>(pbase + b * n2 + c_tile0 - 1) : INVALID_LABEL;
             }
         }
         if (has_up) {
             const bool row_ok = (b_wave0 - 1) < n1;
-            const T* row = pbase + (EDGE ? (row_ok ? (b_wave0 - 1) : 0) : (b_wave0 - 1)) * n2;
-            load_strip<T, VPL>(EDGE, row, row_ok, c0, n2, dup);
+            const T* row = pbase + (EDGE ? (row_ok ? (b_wave0 - 1) : 0) : (b_wave0 - 1)) * n2 + c_tile0;
+            load_strip<T, VPL>(EDGE, row, row_ok, lane_off, c0, n2, dup);
         }
     };
 
@@ -512,8 +527,8 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const boo
             } else {
                 L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
             }
-            lds_label_add<MOM2>(A, S, F, first_label, L, 0u, last, (uint32_t)b0, (uint32_t)(b0 + nb - 1), 0u,
-                                (uint32_t)(nc - 1));
+            lds_label_add<MOM2, LDS, LocalSums>(A, S, F, first_label, L, 0u, last, (uint32_t)b0, (uint32_t)(b0 + nb - 1), 0u,
+                                                (uint32_t)(nc - 1));
         }
     } else {
         // every column closes its run [a0, last]: RB*VPL dense blocks of 64 records, consumed as they come
@@ -561,7 +576,17 @@ __global__ void __launch_bounds__(WAVES * 64, TA_MINWAVES) sweep_kernel(SweepArg
     __syncthreads();
 
     const int64_t tiles_c = (A.n2 + TC - 1) / TC, tiles_b = (A.n1 + TB - 1) / TB;
+#ifdef TA_XCD_REMAP
+    // Workgroups are dealt round-robin over the 8 XCDs (speed only, never correctness): give each
+    // XCD a contiguous range of tile ids so tiles that share halo rows/planes share an L2.
+    int64_t t;
+    {
+        const int64_t nwg = gridDim.x, orig = blockIdx.x, xcd = orig % 8, q = nwg / 8, rr = nwg % 8;
+        t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + orig / 8;
+    }
+#else
     int64_t t = blockIdx.x;
+#endif
     const int64_t tc = t % tiles_c; t /= tiles_c;
     const int64_t tb = t % tiles_b;
     const int64_t ta_ = t / tiles_b;
