@@ -66,9 +66,9 @@ constexpr int PPROBE = 32;
 constexpr int MAX_TILE_PLANES = 64;
 constexpr uint32_t LABEL_LIMIT = 1u << 28;    // max_label < 2^28: the two top bits of a record word are free
 
-struct __attribute__((aligned(16))) WaveLds {
-    uint2 fq[QCAP];               // faces: {voxel, neighbour | axis << 30}
-    uint2 rq[QCAP];               // runs : {label, c_loc | b_loc << 10 | a0 << 14 | n << 20}
+struct __attribute__((aligned(16))) WaveLds {     // struct-of-arrays rings: two dword stores, no 64-bit register pairs
+    uint32_t fqv[QCAP], fqp[QCAP];   // faces: voxel, neighbour | axis << 30
+    uint32_t rql[QCAP], rqc[QCAP];   // runs : label, c_loc | b_loc << 10 | a0 << 14 | n << 20
 };
 
 // Workgroup tables.  Moments are kept in TILE-LOCAL coordinates (a < 64 planes, b < 16 rows,
@@ -261,11 +261,12 @@ __device__ __forceinline__ void consume_rings(const SweepArgs& A, LDS& S, const 
         for (;;) {
             const int cnt = ftail - fhead;
             if (cnt < 64 && !(all && cnt > 0)) break;
-            const uint2 rec = W.fq[(fhead + lane) & (QCAP - 1)];
+            const int qi = (fhead + lane) & (QCAP - 1);
+            const uint32_t recx = W.fqv[qi], recy = W.fqp[qi];
             const bool act = lane < cnt;
             fhead += cnt < 64 ? cnt : 64;
             if (TA_ABLATE == 0 && act) {
-                const uint32_t v = rec.x, pv = rec.y & 0x3fffffffu, axis = rec.y >> 30;
+                const uint32_t v = recx, pv = recy & 0x3fffffffu, axis = recy >> 30;
                 if (v != INVALID_LABEL && pv < LABEL_LIMIT) lds_pair_add(A, S, pv, v, axis, 1u);
             }
         }
@@ -273,11 +274,11 @@ __device__ __forceinline__ void consume_rings(const SweepArgs& A, LDS& S, const 
     for (;;) {
         const int cnt = rtail - rhead;
         if (cnt < 64 && !(all && cnt > 0)) break;
-        const uint2 rec = W.rq[(rhead + lane) & (QCAP - 1)];
+        const int qi = (rhead + lane) & (QCAP - 1);
+        const uint32_t label = W.rql[qi], code = W.rqc[qi];
         const bool act = lane < cnt;
         rhead += cnt < 64 ? cnt : 64;
         if (TA_ABLATE == 0 && act) {
-            const uint32_t label = rec.x, code = rec.y;
             const uint32_t cl = code & 1023u, bl = (code >> 10) & 15u, a0l = (code >> 14) & 63u, n = code >> 20;
             if (label != INVALID_LABEL && n != 0u) {
                 const uint32_t a1l = a0l + n - 1u;
@@ -418,46 +419,57 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const boo
             // pass.  A row whose records might not fit in the rings (never seen on tissue, only on
             // noise) runs one block per pass, each followed by the same single consumer site.
             const bool overflow = (ftail - fhead) + nface > QCAP || (rtail - rhead) + nrun > QCAP;
-            const int npass = overflow ? 3 * VPL : 1;
-#pragma nounroll
-            for (int pass = 0; pass < npass; ++pass) {
-                int fo = ftail, ro = rtail;
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) {
-                    const uint32_t v = cur[r][j];
-                    if (ADJ) {
-                        if ((r > 0 || has_up) && (!overflow || pass == 3 * j)) {
-                            const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];
-                            if (v != pv) W.fq[(fo + (int)mbcnt64(mb[j])) & (QCAP - 1)] = make_uint2(v, pv | (1u << 30));
-                            fo += __popcll(mb[j]);
-                        }
-                        if (!overflow || pass == 3 * j + 1) {
-                            if (v != pcv[j]) W.fq[(fo + (int)mbcnt64(mc[j])) & (QCAP - 1)] = make_uint2(v, pcv[j] | (2u << 30));
-                            fo += __popcll(mc[j]);
-                        }
-                    }
-                    if (!overflow || pass == 3 * j + 2) {
-                        // axis 0: closes the column's open run (length ploc - a0; 0 for the plane before the tile)
-                        const uint32_t o = runlab[r][j];
-                        const uint32_t i = mbcnt64(ma[j]);
-                        const uint32_t sh = 8u * (j % 4);
-                        const uint32_t a0 = (a0w[r][j / 4] >> sh) & 0xffu;
-                        if (v != o) {
-                            if (ADJ) W.fq[(fo + (int)i) & (QCAP - 1)] = make_uint2(v, o);
-                            W.rq[(ro + (int)i) & (QCAP - 1)] =
-                                make_uint2(o, (lane_c + j) | ((uint32_t)(w * RB + r) << 10) | (a0 << 14) | ((ploc - a0) << 20));
-                            a0w[r][j / 4] = (a0w[r][j / 4] & ~(0xffu << sh)) | (ploc << sh);
-                            runlab[r][j] = v;
-                        }
-                        const int n = __popcll(ma[j]);
-                        if (ADJ) fo += n;
-                        ro += n;
-                    }
-                }
-                ftail = fo; rtail = ro;
+// one row's blocks; GUARD(k) selects which blocks run in this pass (always true on the fast path)
+#define TA_EMIT_ROW(GUARD)                                                                                  \
+            {                                                                                                \
+                int fo = ftail, ro = rtail;                                                                  \
+                _Pragma("unroll") for (int j = 0; j < VPL; ++j) {                                            \
+                    const uint32_t v = cur[r][j];                                                            \
+                    if (ADJ) {                                                                               \
+                        if ((r > 0 || has_up) && GUARD(3 * j)) {                                             \
+                            const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];                   \
+                            if (v != pv) {                                                                   \
+                                const int q_ = (fo + (int)mbcnt64(mb[j])) & (QCAP - 1);                      \
+                                W.fqv[q_] = v; W.fqp[q_] = pv | (1u << 30);                                  \
+                            }                                                                                \
+                            fo += __popcll(mb[j]);                                                           \
+                        }                                                                                    \
+                        if (GUARD(3 * j + 1)) {                                                              \
+                            if (v != pcv[j]) {                                                               \
+                                const int q_ = (fo + (int)mbcnt64(mc[j])) & (QCAP - 1);                      \
+                                W.fqv[q_] = v; W.fqp[q_] = pcv[j] | (2u << 30);                              \
+                            }                                                                                \
+                            fo += __popcll(mc[j]);                                                           \
+                        }                                                                                    \
+                    }                                                                                        \
+                    if (GUARD(3 * j + 2)) {                                                                  \
+                        /* axis 0: closes the column's open run (length ploc - a0; 0 for the plane before the tile) */ \
+                        const uint32_t o = runlab[r][j];                                                     \
+                        if (v != o) {                                                                        \
+                            const uint32_t i = mbcnt64(ma[j]);                                               \
+                            const uint32_t sh = 8u * (j % 4);                                                \
+                            const uint32_t a0 = (a0w[r][j / 4] >> sh) & 0xffu;                               \
+                            if (ADJ) { const int q_ = (fo + (int)i) & (QCAP - 1); W.fqv[q_] = v; W.fqp[q_] = o; } \
+                            const int q2_ = (ro + (int)i) & (QCAP - 1);                                      \
+                            W.rql[q2_] = o;                                                                  \
+                            W.rqc[q2_] = (lane_c + j) | ((uint32_t)(w * RB + r) << 10) | (a0 << 14) | ((ploc - a0) << 20); \
+                            a0w[r][j / 4] = (a0w[r][j / 4] & ~(0xffu << sh)) | (ploc << sh);                 \
+                            runlab[r][j] = v;                                                                \
+                        }                                                                                    \
+                        const int n = __popcll(ma[j]);                                                       \
+                        if (ADJ) fo += n;                                                                    \
+                        ro += n;                                                                             \
+                    }                                                                                        \
+                }                                                                                            \
+                ftail = fo; rtail = ro;                                                                      \
+            }
+#define TA_GUARD_ALL(k) true
+#define TA_GUARD_PASS(k) (pass == (k))
+            if (!overflow) {
+                TA_EMIT_ROW(TA_GUARD_ALL)
 #ifdef TA_STAMPS
                 const uint64_t t2 = TA_T();
-                if (pass == 0) { tk_emit += t2 - t1; tk_evrows += 1; }
+                tk_emit += t2 - t1; tk_evrows += 1;
 #endif
                 if (ftail - fhead >= 64 || rtail - rhead >= 64) {
                     __builtin_amdgcn_wave_barrier();
@@ -467,7 +479,21 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const boo
 #ifdef TA_STAMPS
                 tk_cons += TA_T() - t2;
 #endif
+            } else {
+                // never seen on tissue, only on noise: one block per pass so the rings cannot overflow
+#pragma nounroll
+                for (int pass = 0; pass < 3 * VPL; ++pass) {
+                    TA_EMIT_ROW(TA_GUARD_PASS)
+                    if (ftail - fhead >= 64 || rtail - rhead >= 64) {
+                        __builtin_amdgcn_wave_barrier();
+                        consume_rings<ADJ, MOM2, LDS>(A, S, F, w, lane, fhead, ftail, rhead, rtail, false);
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                }
             }
+#undef TA_EMIT_ROW
+#undef TA_GUARD_ALL
+#undef TA_GUARD_PASS
         }
 #ifdef TA_STAMPS
         const uint64_t t4 = TA_T();
@@ -537,8 +563,9 @@ __device__ __forceinline__ void wave_sweep(const SweepArgs& A, LDS& S, const boo
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
                 const uint32_t a0 = (a0w[r][j / 4] >> (8u * (j % 4))) & 0xffu;
-                W.rq[(rtail + lane) & (QCAP - 1)] =
-                    make_uint2(runlab[r][j], (lane_c + j) | ((uint32_t)(w * RB + r) << 10) | (a0 << 14) | ((last + 1u - a0) << 20));
+                const int q_ = (rtail + lane) & (QCAP - 1);
+                W.rql[q_] = runlab[r][j];
+                W.rqc[q_] = (lane_c + j) | ((uint32_t)(w * RB + r) << 10) | (a0 << 14) | ((last + 1u - a0) << 20);
                 rtail += 64;
                 if (QCAP < 64 * (VPL + 1) || j == VPL - 1) {
                     __builtin_amdgcn_wave_barrier();
