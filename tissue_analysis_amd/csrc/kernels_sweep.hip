@@ -55,12 +55,15 @@ namespace ta {
 #define TA_PREFETCH 1
 #endif
 #ifndef TA_MINWAVES
-#define TA_MINWAVES 3             // waves per SIMD the register allocator must leave room for
+#define TA_MINWAVES 4             // waves per SIMD the register allocator must leave room for
 #endif
 constexpr int WAVES = TA_WAVES;   // waves per workgroup, stacked along axis 1
 constexpr int QCAP = TA_QCAP;     // per-wave ring capacity (records); one block adds <= 64
 constexpr int LSLOTS = TA_LSLOTS; // label table slots per workgroup
 constexpr int PSLOTS = TA_PSLOTS; // pair table slots per workgroup
+constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
+constexpr int LSLOTS_LOG2 = ilog2_c(LSLOTS), PSLOTS_LOG2 = ilog2_c(PSLOTS);
+static_assert((1 << LSLOTS_LOG2) == LSLOTS && (1 << PSLOTS_LOG2) == PSLOTS, "table sizes must be powers of two");
 constexpr int LPROBE = 16;        // max probes before spilling to global atomics
 constexpr int PPROBE = 32;
 constexpr int MAX_TILE_PLANES = 64;
@@ -179,7 +182,7 @@ __device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, const 
                                               const SUMS& L, uint32_t mna, uint32_t mxa, uint32_t mnb,
                                               uint32_t mxb, uint32_t mnc, uint32_t mxc) {
     constexpr int NW = MOM2 ? 6 : 2;
-    uint32_t h = hash_u32(label) & (LSLOTS - 1);
+    uint32_t h = (label * 0x9E3779B1u) >> (32 - LSLOTS_LOG2);          // Fibonacci hashing: top bits of one multiply
     int slot = -1;
 #pragma nounroll
     for (int probe = 0; probe < LPROBE; ++probe) {
@@ -227,7 +230,7 @@ __device__ __forceinline__ void lds_pair_add(const SweepArgs& A, LDS& S, uint32_
                                              uint32_t axis, uint32_t count) {
     const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
     const uint64_t key = ((uint64_t)lo << 32) | hi;
-    uint32_t h = hash_pair(lo, hi) & (PSLOTS - 1);
+    uint32_t h = ((lo * 0x9E3779B1u) ^ (hi * 0x85EBCA6Bu)) * 0xC2B2AE35u >> (32 - PSLOTS_LOG2);
     int slot = -1;
 #pragma nounroll
     for (int probe = 0; probe < PPROBE; ++probe) {
