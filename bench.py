@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--config", default=None, help="override: C2/C3/C4/C5 on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-planes", type=int, default=0)
+    ap.add_argument("--dims", type=int, nargs=3, default=None, help="rehearsal: override the volume shape")
     args = ap.parse_args()
 
     import torch
@@ -90,11 +91,19 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run" % (n, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X GPU (no CPU fallback)")
+    # TA_BENCH_BACKEND=gloo rehearses the N>1 path on a box with fewer GPUs than ranks (RCCL cannot
+    # put two ranks on one device); the real runs use nccl (= RCCL over xGMI), one rank per GPU.
+    backend = os.environ.get("TA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     if n > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world,
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.config:
         c = synth.CONFIGS[args.config]
@@ -103,6 +112,8 @@ def main():
     else:
         cfg = weak_config(n)
         feats = _capi.F_ALL
+    if args.dims:
+        cfg = dict(cfg, dims=tuple(args.dims), name=cfg["name"] + "-custom")
     dims, dtype = cfg["dims"], np.dtype(cfg["dtype"])
 
     ctx = dev.torch_context(local_rank)
@@ -129,8 +140,6 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         job.step()
-        if False:
-            pass
     barrier()
     dt = time.perf_counter() - t0
     # per-kernel durations from the HIP events of the last steps (events live on the launch stream)
@@ -142,7 +151,7 @@ def main():
         adj_ms.append(t["ms_adjacency"])
     bytes_read = ctx.timing()["bytes_read"]
 
-    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+    tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
     if n > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())

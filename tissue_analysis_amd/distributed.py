@@ -124,7 +124,7 @@ class SlabJob(object):
             rank = dist.get_rank(self.group)
             # drop this rank's own block (already in the local list), merge the others
             kall[rank * m:(rank + 1) * m] = EMPTY_KEY
-            torch.cuda.current_stream().synchronize()
+            # the context launches on torch's current stream, which already waits for the collective
             self.ctx.adjacency_merge(kall.data_ptr(), fall.data_ptr(), kall.shape[0])
 
     def result_counts(self):
