@@ -124,7 +124,10 @@ class SlabJob(object):
             rank = dist.get_rank(self.group)
             # drop this rank's own block (already in the local list), merge the others
             kall[rank * m:(rank + 1) * m] = EMPTY_KEY
-            # the context launches on torch's current stream, which already waits for the collective
+            # With nccl (RCCL) the current stream -- which the context launches on -- already waits for
+            # the collective; gloo moves device tensors through the host on its own streams.
+            if dist.get_backend(self.group) != "nccl":
+                torch.cuda.synchronize()
             self.ctx.adjacency_merge(kall.data_ptr(), fall.data_ptr(), kall.shape[0])
 
     def result_counts(self):
