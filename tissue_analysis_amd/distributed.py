@@ -67,9 +67,9 @@ def allgather_pairs(keys, faces, group=None):
     import torch.distributed as dist
     world = dist.get_world_size(group)
     n = torch.tensor([keys.shape[0]], dtype=torch.int64, device=keys.device)
-    sizes = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(sizes, n, group=group)
-    m = int(max(int(s.item()) for s in sizes))
+    sizes = torch.zeros(world, dtype=torch.int64, device=keys.device)
+    dist.all_gather_into_tensor(sizes, n, group=group)
+    m = int(sizes.max().item())                      # one host sync for all ranks' counts
     kpad = torch.full((max(m, 1),), EMPTY_KEY, dtype=torch.int64, device=keys.device)
     fpad = torch.zeros((max(m, 1), 3), dtype=torch.int64, device=keys.device)
     kpad[:keys.shape[0]] = keys
