@@ -140,11 +140,13 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         job.step()
+    job.finish()          # collective: read the (deferred) verdict of the exchange inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     # per-kernel durations from the HIP events of the last steps (events live on the launch stream)
     for _ in range(min(5, max(1, args.steps))):
         job.step()
+        job.finish()
         torch.cuda.synchronize()
         t = ctx.timing()
         sweep_ms.append(t["ms_sweep"])

@@ -45,7 +45,7 @@ extern "C" {
 #define TA_EHIP       -2  /* HIP runtime error (text in ta_last_error)                   */
 #define TA_ENOMEM     -3  /* host or device allocation failed                            */
 #define TA_ERANGE     -4  /* the volume holds a label above max_label                    */
-#define TA_ECAPACITY  -5  /* adjacency table could not grow any further                  */
+#define TA_ECAPACITY  -5  /* adjacency table / exchange block too small (see the call's doc)  */
 #define TA_ENODEVICE  -6  /* no usable GPU                                               */
 
 /* feature mask of ta_extract() */
@@ -73,6 +73,9 @@ TA_API int ta_ctx_create(int device_id, ta_ctx** out);
 TA_API int ta_ctx_destroy(ta_ctx* ctx);
 TA_API int ta_ctx_set_stream(ta_ctx* ctx, void* hip_stream /* hipStream_t, caller-owned; NULL = own stream */);
 TA_API int ta_ctx_set_option(ta_ctx* ctx, int key, int64_t value);
+/* Current effective value of an option (TA_OPT_PAIR_SLOTS: log2 of the table in use, which may
+ * have grown past the requested size). */
+TA_API int ta_ctx_get_option(ta_ctx* ctx, int key, int64_t* value);
 TA_API int ta_ctx_synchronize(ta_ctx* ctx);
 
 /* Upload a host volume (SIA:225-227 "self.image").  itemsize 2 (uint16) or 4 (uint32).
@@ -143,6 +146,21 @@ TA_API int ta_adjacency_export(ta_ctx* ctx, void* keys_dst_dev, void* faces_dst_
 /* Merge foreign pair lists (other ranks' ta_adjacency_device output, gathered by the host with
  * RCCL) into this context's adjacency: sums face counts of equal keys. */
 TA_API int ta_adjacency_merge(ta_ctx* ctx, const void* keys_dev, const void* faces_dev, int64_t npairs);
+
+/* ---- stream-ordered adjacency exchange (no host round trip) ------------------
+ * One exchange block per rank, uint64 words, TA_EXCHANGE_WORDS(capacity) long:
+ *   [0] pair count (may exceed capacity)  [1] status bits  [2..2+cap) keys, ~0 padded
+ *   [2+cap .. 2+4*cap) faces[cap][3]
+ * ta_adjacency_pack writes this rank's block from the last extraction; the host all-gathers the
+ * blocks (RCCL, same stream); ta_adjacency_merge_blocks rebuilds the context's adjacency from ALL
+ * nblocks blocks (this rank's included).  Both only enqueue work.  Range / table-overflow flags
+ * travel in the status word, so every rank reaches the same verdict: the next result getter
+ * (ta_adjacency_size / _get / _device, ta_get_labels) returns TA_ECAPACITY when some block or
+ * table was too small -- raise the capacity (or TA_OPT_PAIR_SLOTS) on every rank and redo the
+ * step -- and TA_ERANGE when any rank saw a label above max_label. */
+#define TA_EXCHANGE_WORDS(capacity_pairs) (2 + 4 * (int64_t)(capacity_pairs))
+TA_API int ta_adjacency_pack(ta_ctx* ctx, void* block_dev, int64_t capacity_pairs);
+TA_API int ta_adjacency_merge_blocks(ta_ctx* ctx, const void* blocks_dev, int nblocks, int64_t capacity_pairs);
 
 /* Synthetic workload generator, bit-identical to tissue_analysis_amd/synth.py:
  * writes planes [a_begin, a_begin+a_count) of the dims[] Voronoi volume to dev_out (dense C).

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q):
+def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None, pair_slots=0):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -29,8 +29,10 @@ def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q):
         lo, hi = tad.slab_range(dims[0], world, rank)
         halo = 1 if lo > 0 else 0
         vol, max_label = dev.synth_slab(ctx, dims, dtype, n_cells, seed, lo - halo, hi, device=0)
+        if pair_slots and rank == 1:    # one rank starts with a table far too small: sizes must be agreed on
+            ctx.set_option(_capi.OPT_PAIR_SLOTS, pair_slots)
         job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=lo, has_low_halo=bool(halo), max_label=max_label,
-                          features=_capi.F_ALL, group=dist.group.WORLD, device=0)
+                          features=_capi.F_ALL, group=dist.group.WORLD, device=0, exchange_capacity=capacity)
         job.step()
         job.step()                      # a second step must give the same answer (tables self-clean)
         got = job.result_arrays()
@@ -40,19 +42,28 @@ def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q):
                  ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces"))
         bad = [k for k in ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces")
                if not (got[k].shape == want[k].shape and np.array_equal(got[k], want[k]))]
+        if capacity:                    # a block that small must have forced exactly one collective redo
+            ok = ok and job.redo_count == 1
+            bad.append("redo_count=%d" % job.redo_count)
         q.put((rank, bool(ok), bad))
         ctx.close()
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dims,n_cells,dtype_name", [((37, 40, 264), 50, "uint32"), ((20, 24, 520), 30, "uint16")])
-def test_two_ranks_on_one_gpu_match_unsharded(dims, n_cells, dtype_name):
+@pytest.mark.parametrize("dims,n_cells,dtype_name,capacity,pair_slots", [
+    ((37, 40, 264), 50, "uint32", None, 0),
+    ((20, 24, 520), 30, "uint16", None, 0),
+    ((37, 40, 264), 50, "uint32", 8, 0),        # exchange blocks too small: verdict -> re-size -> redo
+    ((37, 40, 264), 50, "uint32", None, 6),     # rank 1 starts with a 64-slot table: grown and agreed on
+])
+def test_two_ranks_on_one_gpu_match_unsharded(dims, n_cells, dtype_name, capacity, pair_slots):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29800 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, n_cells, 61, dtype_name, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, n_cells, 61, dtype_name, q, capacity, pair_slots))
+             for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=240) for _ in range(world)]

@@ -23,12 +23,18 @@ OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS = 1, 2, 3
 # every symbol include/tissue_scan.h declares
 SYMBOLS = (
     "ta_version", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
-    "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_synchronize", "ta_volume_set",
+    "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_get_option", "ta_ctx_synchronize", "ta_volume_set",
     "ta_volume_set_device", "ta_volume_max_label", "ta_extract", "ta_get_labels",
     "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_debug_counters", "ta_bind_accumulators",
-    "ta_accumulators_device", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge", "ta_synth_voronoi",
+    "ta_accumulators_device", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge",
+    "ta_adjacency_pack", "ta_adjacency_merge_blocks", "ta_synth_voronoi",
     "ta_device_malloc", "ta_device_free", "ta_memcpy_d2h", "ta_memcpy_h2d",
 )
+
+
+def exchange_words(capacity_pairs):
+    """uint64 words of one exchange block (TA_EXCHANGE_WORDS in include/tissue_scan.h)."""
+    return 2 + 4 * int(capacity_pairs)
 
 
 class TissueScanError(RuntimeError):
@@ -61,6 +67,7 @@ def load():
         "ta_ctx_destroy": (ci, [vp]),
         "ta_ctx_set_stream": (ci, [vp, vp]),
         "ta_ctx_set_option": (ci, [vp, ci, i64]),
+        "ta_ctx_get_option": (ci, [vp, ci, P(i64)]),
         "ta_ctx_synchronize": (ci, [vp]),
         "ta_volume_set": (ci, [vp, vp, ci, P(i64), P(i64)]),
         "ta_volume_set_device": (ci, [vp, vp, ci, P(i64), i64, ci]),
@@ -76,6 +83,8 @@ def load():
         "ta_adjacency_device": (ci, [vp, P(vp), P(vp), P(i64)]),
         "ta_adjacency_export": (ci, [vp, vp, vp, i64]),
         "ta_adjacency_merge": (ci, [vp, vp, vp, i64]),
+        "ta_adjacency_pack": (ci, [vp, vp, i64]),
+        "ta_adjacency_merge_blocks": (ci, [vp, vp, ci, i64]),
         "ta_synth_voronoi": (ci, [vp, vp, ci, P(i64), i64, i64, vp, P(ctypes.c_int32), vp]),
         "ta_device_malloc": (ci, [vp, u64, P(vp)]),
         "ta_device_free": (ci, [vp, vp]),
@@ -161,6 +170,11 @@ class Context(object):
     def set_option(self, key, value):
         _check(self._lib.ta_ctx_set_option(self._h, int(key), int(value)))
 
+    def get_option(self, key):
+        v = ctypes.c_int64(0)
+        _check(self._lib.ta_ctx_get_option(self._h, int(key), ctypes.byref(v)))
+        return int(v.value)
+
     def synchronize(self):
         _check(self._lib.ta_ctx_synchronize(self._h))
 
@@ -202,6 +216,12 @@ class Context(object):
         _check(self._lib.ta_get_labels(self._h, count.ctypes.data, bbox.ctypes.data, sum1.ctypes.data,
                                        sum2.ctypes.data))
         return count, bbox, sum1, sum2
+
+    def adjacency_size(self):
+        """Pair count of the last extraction (drains the stream, validates its flags)."""
+        n = ctypes.c_int64(0)
+        _check(self._lib.ta_adjacency_size(self._h, ctypes.byref(n)))
+        return int(n.value)
 
     def adjacency(self):
         """(lo u32[n], hi u32[n], faces u64[n,3]) sorted by (lo, hi)."""
@@ -247,6 +267,15 @@ class Context(object):
     def adjacency_merge(self, keys_ptr, faces_ptr, npairs):
         _check(self._lib.ta_adjacency_merge(self._h, ctypes.c_void_p(int(keys_ptr) if keys_ptr else 0),
                                             ctypes.c_void_p(int(faces_ptr) if faces_ptr else 0), int(npairs)))
+
+    def adjacency_pack(self, block_ptr, capacity):
+        """Enqueue: write this rank's exchange block (exchange_words(capacity) uint64 words)."""
+        _check(self._lib.ta_adjacency_pack(self._h, ctypes.c_void_p(int(block_ptr)), int(capacity)))
+
+    def adjacency_merge_blocks(self, blocks_ptr, nblocks, capacity):
+        """Enqueue: rebuild the adjacency from all ranks' gathered exchange blocks."""
+        _check(self._lib.ta_adjacency_merge_blocks(self._h, ctypes.c_void_p(int(blocks_ptr)), int(nblocks),
+                                                   int(capacity)))
 
     # -- synthetic workload + raw memory
     def synth_voronoi(self, dev_ptr, dtype, dims, a_begin, a_count, seeds, grid, ell=None):

@@ -194,6 +194,68 @@ void launch_pairs_insert(hipStream_t s, const PairTable& pt, const uint64_t* key
                        flags);
 }
 
+// ---- multi-GPU exchange: fixed-capacity blocks, no host round trip (layout in ta_device.h) ----
+__global__ void __launch_bounds__(256) pairs_pack_kernel(const uint64_t* keys, const uint64_t* faces,
+                                                         const uint32_t* cursor, const uint32_t* flags,
+                                                         uint64_t* block, uint64_t cap) {
+    const uint64_t n = *cursor;
+    uint64_t* bk = block + XHDR;
+    uint64_t* bf = block + XHDR + cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        block[0] = n;
+        block[1] = (flags[FLAG_RANGE] ? XSTATUS_RANGE : 0) | (flags[FLAG_PAIR_OVERFLOW] ? XSTATUS_PAIR_OVERFLOW : 0);
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const bool live = i < n;
+        bk[i] = live ? keys[i] : EMPTY_KEY;
+        bf[3 * i + 0] = live ? faces[3 * i + 0] : 0;
+        bf[3 * i + 1] = live ? faces[3 * i + 1] : 0;
+        bf[3 * i + 2] = live ? faces[3 * i + 2] : 0;
+    }
+}
+
+void launch_pairs_pack(hipStream_t s, const uint64_t* keys, const uint64_t* faces, const uint32_t* cursor,
+                       const uint32_t* flags, uint64_t* block, uint64_t cap) {
+    uint64_t blocks = (cap + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pairs_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, keys, faces, cursor, flags,
+                       block, cap);
+}
+
+__global__ void __launch_bounds__(256) pairs_insert_blocks_kernel(PairTable pt, const uint64_t* blocks,
+                                                                  int nblocks, uint64_t cap, uint32_t* flags) {
+    const uint64_t stride = XHDR + 4 * cap, total = (uint64_t)nblocks * cap;
+    for (uint64_t idx = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t b = idx / cap, i = idx - b * cap;
+        const uint64_t* blk = blocks + b * stride;
+        const uint64_t n = blk[0];
+        if (i == 0) {                                     // one thread per block carries the header over
+            const uint64_t st = blk[1];
+            if (st & XSTATUS_RANGE) atomicOr(&flags[FLAG_RANGE], 1u);
+            if (st & XSTATUS_PAIR_OVERFLOW) atomicOr(&flags[FLAG_PAIR_OVERFLOW], 1u);
+            if (n > cap) atomicOr(&flags[FLAG_EXCHANGE_OVERFLOW], 1u);
+        }
+        if (i >= n) continue;
+        const uint64_t k = blk[XHDR + i];
+        if (k == EMPTY_KEY) continue;
+        const uint64_t* f = blk + XHDR + cap + 3 * i;
+        pair_add_global(pt, (uint32_t)(k >> 32), (uint32_t)k, f[0], f[1], f[2], flags);
+    }
+}
+
+void launch_pairs_insert_blocks(hipStream_t s, const PairTable& pt, const uint64_t* blocks, int nblocks,
+                                uint64_t cap, uint32_t* flags) {
+    const uint64_t total = (uint64_t)nblocks * cap;
+    if (total == 0) return;
+    uint64_t grid = (total + 255) / 256;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(pairs_insert_blocks_kernel, dim3((unsigned)grid), dim3(256), 0, s, pt, blocks, nblocks,
+                       cap, flags);
+}
+
 __global__ void __launch_bounds__(256) pairs_clear_kernel(PairTable pt) {
     const uint64_t cap = (uint64_t)pt.mask + 1;
     for (uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; h < cap;

@@ -87,6 +87,7 @@ struct ta_ctx {
     int tile_planes = 0;
     uint32_t feature_mask = 0;
     bool extracted = false, checked = false;
+    bool exchanged = false;                             // adjacency rebuilt by ta_adjacency_merge_blocks
     int64_t npairs = 0;
     std::vector<uint64_t> h_keys, h_faces;              // sorted host copy for ta_adjacency_get
     bool host_pairs_ready = false;
@@ -176,6 +177,18 @@ int run_extract(ta_ctx* c) {
 int finish_extract(ta_ctx* c) {
     if (!c->extracted) return fail(TA_EINVAL, "no extraction has been run on this context");
     if (c->checked) return TA_OK;
+    if (c->exchanged) {       // the list came from other ranks too: a re-run is the host's call
+        TA_HIP(hipStreamSynchronize(c->stream));
+        if (c->h_small[ta::FLAG_RANGE])
+            return fail(TA_ERANGE, "a rank saw a label above max_label=%u", c->max_label);
+        if (c->h_small[ta::FLAG_EXCHANGE_OVERFLOW])
+            return fail(TA_ECAPACITY, "an exchange block was too small for a rank's pair list");
+        if (c->h_small[ta::FLAG_PAIR_OVERFLOW])
+            return fail(TA_ECAPACITY, "adjacency table overflow on some rank (2^%d slots here)", c->pair_log2);
+        c->npairs = (int64_t)c->h_small[ta::NFLAGS];
+        c->checked = true;
+        return TA_OK;
+    }
     for (int attempt = 0; attempt < 8; ++attempt) {
         TA_HIP(hipStreamSynchronize(c->stream));
         if (c->h_small[ta::FLAG_RANGE])
@@ -277,6 +290,16 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
             c->opt_pair_log2 = (int)value; return TA_OK;
         default:
             return fail(TA_EINVAL, "unknown option key %d", key);
+    }
+}
+
+TA_API int ta_ctx_get_option(ta_ctx* c, int key, int64_t* value) {
+    if (!c || !value) return fail(TA_EINVAL, "NULL argument");
+    switch (key) {
+        case TA_OPT_IMPL: *value = c->impl; return TA_OK;
+        case TA_OPT_TILE_PLANES: *value = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(); return TA_OK;
+        case TA_OPT_PAIR_SLOTS: *value = c->pkeys.p ? c->pair_log2 : c->opt_pair_log2; return TA_OK;
+        default: return fail(TA_EINVAL, "unknown option key %d", key);
     }
 }
 
@@ -405,6 +428,7 @@ TA_API int ta_extract(ta_ctx* c, uint32_t feature_mask, uint32_t max_label) {
     }
     c->extracted = true;
     c->checked = false;
+    c->exchanged = false;
     c->host_pairs_ready = false;
     return run_extract(c);
 }
@@ -576,6 +600,41 @@ TA_API int ta_adjacency_merge(ta_ctx* c, const void* keys_dev, const void* faces
     if (c->h_small[ta::FLAG_PAIR_OVERFLOW])
         return fail(TA_ECAPACITY, "adjacency table overflow while merging (2^%d slots); raise TA_OPT_PAIR_SLOTS", c->pair_log2);
     c->npairs = (int64_t)c->h_small[ta::NFLAGS];
+    c->host_pairs_ready = false;
+    return TA_OK;
+}
+
+TA_API int ta_adjacency_pack(ta_ctx* c, void* block_dev, int64_t capacity_pairs) {
+    if (!c || !block_dev) return fail(TA_EINVAL, "NULL argument");
+    if (capacity_pairs < 1) return fail(TA_EINVAL, "capacity_pairs must be >= 1");
+    if (!c->extracted || !(c->feature_mask & TA_F_ADJACENCY))
+        return fail(TA_EINVAL, "no extraction with adjacency has been run on this context");
+    if (c->exchanged) return fail(TA_EINVAL, "the adjacency of this extraction was already exchanged");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    ta::launch_pairs_pack(c->stream, (const uint64_t*)c->out_keys.p, (const uint64_t*)c->out_faces.p, cursor_dev(c),
+                          flags_dev(c), (uint64_t*)block_dev, (uint64_t)capacity_pairs);
+    TA_HIP(hipGetLastError());
+    return TA_OK;
+}
+
+TA_API int ta_adjacency_merge_blocks(ta_ctx* c, const void* blocks_dev, int nblocks, int64_t capacity_pairs) {
+    if (!c || !blocks_dev) return fail(TA_EINVAL, "NULL argument");
+    if (nblocks < 1 || capacity_pairs < 1) return fail(TA_EINVAL, "nblocks and capacity_pairs must be >= 1");
+    if (!c->extracted || !(c->feature_mask & TA_F_ADJACENCY))
+        return fail(TA_EINVAL, "no extraction with adjacency has been run on this context");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    // the collect of the extraction left the table clean: rebuild it from every rank's block
+    ta::PairTable pt = pair_table(c);
+    TA_HIP(hipMemsetAsync(c->small.p, 0, SMALL_WORDS * sizeof(uint32_t), c->stream));
+    ta::launch_pairs_insert_blocks(c->stream, pt, (const uint64_t*)blocks_dev, nblocks, (uint64_t)capacity_pairs,
+                                   flags_dev(c));
+    ta::launch_pairs_collect(c->stream, pt, (uint64_t*)c->out_keys.p, (uint64_t*)c->out_faces.p, cursor_dev(c));
+    TA_HIP(hipMemcpyAsync(c->h_small, c->small.p, SMALL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
+    TA_HIP(hipGetLastError());
+    c->exchanged = true;
+    c->checked = false;
     c->host_pairs_ready = false;
     return TA_OK;
 }

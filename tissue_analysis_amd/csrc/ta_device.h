@@ -14,7 +14,14 @@ constexpr int NSUM = 10;                            // count, s0,s1,s2, s00,s01,
 constexpr int NBOX = 6;                             // min0,min1,min2,-max0,-max1,-max2
 
 // flag words written by kernels, read back by the host after the stream drains
-enum { FLAG_RANGE = 0, FLAG_PAIR_OVERFLOW = 1, FLAG_LDS_LABEL_SPILL = 2, FLAG_LDS_PAIR_SPILL = 3, NFLAGS = 16 };
+enum { FLAG_RANGE = 0, FLAG_PAIR_OVERFLOW = 1, FLAG_LDS_LABEL_SPILL = 2, FLAG_LDS_PAIR_SPILL = 3,
+       FLAG_EXCHANGE_OVERFLOW = 4, NFLAGS = 16 };
+
+// Exchange block of one rank (multi-GPU adjacency merge), u64 words:
+//   [0] pair count n (may exceed the capacity: receivers flag the overflow)   [1] status bits
+//   [2 .. 2+cap) keys, EMPTY_KEY padded        [2+cap .. 2+4*cap) faces[cap][3]
+constexpr int XHDR = 2;
+constexpr uint64_t XSTATUS_RANGE = 1, XSTATUS_PAIR_OVERFLOW = 2;
 
 struct PairTable {           // device-global open-addressing hash: key = lo<<32|hi
     uint64_t* keys;          // [cap], EMPTY_KEY when free

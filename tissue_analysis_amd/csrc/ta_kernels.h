@@ -14,6 +14,10 @@ void launch_pairs_collect(hipStream_t s, const PairTable& pt, uint64_t* out_keys
 void launch_pairs_insert(hipStream_t s, const PairTable& pt, const uint64_t* keys, const uint64_t* faces,
                          uint64_t n, uint32_t* flags);
 void launch_pairs_clear(hipStream_t s, const PairTable& pt);
+void launch_pairs_pack(hipStream_t s, const uint64_t* keys, const uint64_t* faces, const uint32_t* cursor,
+                       const uint32_t* flags, uint64_t* block, uint64_t cap);
+void launch_pairs_insert_blocks(hipStream_t s, const PairTable& pt, const uint64_t* blocks, int nblocks,
+                                uint64_t cap, uint32_t* flags);
 void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3], int64_t a_begin,
                   int64_t a_count, const int32_t* seeds_dev, const int32_t grid[3],
                   const int64_t* ell_dev);

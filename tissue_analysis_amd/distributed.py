@@ -85,12 +85,18 @@ class SlabJob(object):
     """One rank's share of a slab-partitioned extraction, device-resident end to end.
 
     step() = fused sweep of the local slab (+ halo) into torch-owned accumulators bound to the
-    C-ABI context, then (world > 1) the RCCL reduce and the adjacency merge.  After step() every
-    rank holds the global per-label rows; rank-local `ctx.adjacency()` holds the global pairs.
+    C-ABI context, then (world > 1) the RCCL reduce and the adjacency exchange.  After step() every
+    rank holds the global per-label rows and `ctx.adjacency()` holds the global pairs.
+
+    In steady state step() only ENQUEUES work (kernels and three collectives on one stream): the
+    adjacency travels in fixed-capacity exchange blocks (ta_adjacency_pack / _merge_blocks) whose
+    capacity was agreed once, synchronously, on the first step.  Overflow and range flags ride in
+    the block headers, so all ranks reach the same verdict; it is read when results are fetched
+    (result_*), which re-sizes and redoes the step if a block or table was too small.
     """
 
     def __init__(self, ctx, vol_tensor, itemsize, a_origin, has_low_halo, max_label, features,
-                 group=None, device=0):
+                 group=None, device=0, exchange_capacity=None):
         import torch
         self.ctx, self.vol, self.group = ctx, vol_tensor, group
         self.has_low_halo = bool(has_low_halo)
@@ -103,39 +109,108 @@ class SlabJob(object):
         ctx.bind_accumulators(self.sums.data_ptr(), self.boxes.data_ptr(), self.max_label,
                               keep=(self.sums, self.boxes))
         self._torch = torch
+        self._cap = int(exchange_capacity) if exchange_capacity else None
+        self._send = self._recv = None
+        self._unverified = False
+        self.redo_count = 0                     # steps repeated because a block / table was too small
 
     def owned_view(self):
         return self.vol[1:] if self.has_low_halo else self.vol
 
-    def step(self):
+    # -- adjacency exchange ------------------------------------------------------------------
+    def _adjacency_wanted(self):
         from . import _capi
+        return self.group is not None and bool(_capi.feature_mask(self.features) & _capi.F_ADJACENCY)
+
+    def _agree_on_sizes(self):
+        """One-off and synchronous: block capacity from the largest local pair list, one table
+        size for all ranks.  Returns True when the extraction had to be repeated."""
+        import torch.distributed as dist
+        from . import _capi
+        torch = self._torch
+        n = self.ctx.adjacency_size()                      # drains; a local table overflow re-runs inside
+        slots = self.ctx.get_option(_capi.OPT_PAIR_SLOTS)
+        t = torch.tensor([n, slots], dtype=torch.int64, device=self.sums.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        nmax, smax = [int(x) for x in t.tolist()]
+        if self._cap is None:
+            self._cap = max(1024, -(-(nmax + nmax // 4 + 1) // 1024) * 1024)
+        again = smax != slots
+        if again:
+            self.ctx.set_option(_capi.OPT_PAIR_SLOTS, smax)
+            self.ctx.extract(self.features, self.max_label)
+        return again
+
+    def _exchange_buffers(self):
+        import torch.distributed as dist
+        from . import _capi
+        torch = self._torch
+        words = _capi.exchange_words(self._cap)
+        world = dist.get_world_size(self.group)
+        if self._send is None or self._send.shape[0] != words:
+            self._send = torch.empty((words,), dtype=torch.int64, device=self.sums.device)
+            self._recv = torch.empty((world * words,), dtype=torch.int64, device=self.sums.device)
+        return world
+
+    def step(self):
+        import torch.distributed as dist
         torch = self._torch
         self.ctx.extract(self.features, self.max_label)
         if self.group is None:
             return
+        adj = self._adjacency_wanted()
+        if adj and (self._cap is None or self._send is None):
+            self._agree_on_sizes()
         allreduce_accumulators(self.sums, self.boxes, self.group)
-        if _capi.feature_mask(self.features) & _capi.F_ADJACENCY:
-            _, _, n = self.ctx.adjacency_device()          # drains the stream, validates the flags
-            keys = torch.empty((max(n, 1),), dtype=torch.int64, device=self.sums.device)
-            faces = torch.empty((max(n, 1), 3), dtype=torch.int64, device=self.sums.device)
-            self.ctx.adjacency_export(keys.data_ptr(), faces.data_ptr(), max(n, 1))
-            kall, fall, m = allgather_pairs(keys[:n], faces[:n], self.group)
-            import torch.distributed as dist
-            rank = dist.get_rank(self.group)
-            # drop this rank's own block (already in the local list), merge the others
-            kall[rank * m:(rank + 1) * m] = EMPTY_KEY
+        if adj:
+            world = self._exchange_buffers()
+            self.ctx.adjacency_pack(self._send.data_ptr(), self._cap)
+            dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
             # With nccl (RCCL) the current stream -- which the context launches on -- already waits for
             # the collective; gloo moves device tensors through the host on its own streams.
             if dist.get_backend(self.group) != "nccl":
                 torch.cuda.synchronize()
-            self.ctx.adjacency_merge(kall.data_ptr(), fall.data_ptr(), kall.shape[0])
+            self.ctx.adjacency_merge_blocks(self._recv.data_ptr(), world, self._cap)
+            self._unverified = True
+
+    def finish(self):
+        """COLLECTIVE (every rank of the group must call it, like step()): read the verdict of the
+        last step; re-size and redo it when an exchange block or an adjacency table was too small
+        anywhere.  The result getters call it, so they are collective too until it has run."""
+        if not self._unverified:
+            return
+        import torch.distributed as dist
+        from . import _capi
+        torch = self._torch
+        for attempt in range(6):
+            status = 0
+            try:
+                self.ctx.adjacency_size()
+            except _capi.TissueScanError as e:
+                if e.code != _capi.TA_ECAPACITY:
+                    raise
+                status = 1
+            t = torch.tensor([status], dtype=torch.int64, device=self.sums.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+            if int(t.item()) == 0:
+                self._unverified = False
+                return
+            self.redo_count += 1
+            self._cap = None
+            self._send = self._recv = None
+            if attempt > 0:                                # re-measured blocks were not enough: grow the tables
+                self.ctx.set_option(_capi.OPT_PAIR_SLOTS, self.ctx.get_option(_capi.OPT_PAIR_SLOTS) + 2)
+            self.step()
+        raise RuntimeError("adjacency exchange still overflows after %d attempts" % 6)
 
     def result_counts(self):
+        self.finish()
         self._torch.cuda.synchronize()
         return self.sums[:, 0].cpu().numpy()
 
     def result_arrays(self):
         """Global result in the host-getter layout (memory-axis order)."""
+        self.finish()
         self._torch.cuda.synchronize()
         out = from_device_layout(self.sums.cpu().numpy(), self.boxes.cpu().numpy())
         out["max_label"] = self.max_label
