@@ -124,9 +124,19 @@ def main():
     halo = 1 if a_lo > 0 else 0
     vol, max_label = dev.synth_slab(ctx, dims, dtype, cfg["n_cells"], cfg["seed"], a_lo - halo, a_hi,
                                     device=local_rank)
-    job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=a_lo, has_low_halo=bool(halo),
-                      max_label=max_label, features=feats, group=(dist.group.WORLD if n > 1 else None),
-                      device=local_rank)
+    # N > 1: two steps in flight on two streams, so that step i's RCCL reduce / adjacency exchange
+    # overlaps step i+1's sweep (TA_BENCH_PIPELINE=1 turns the overlap off)
+    depth = int(os.environ.get("TA_BENCH_PIPELINE", "2")) if n > 1 else 1
+    if depth > 1:
+        job = tad.PipelinedSlabJob(vol, dtype.itemsize, a_origin=a_lo, has_low_halo=bool(halo),
+                                   max_label=max_label, features=feats, group=dist.group.WORLD,
+                                   device=local_rank, depth=depth, tile_planes=args.tile_planes)
+        last_ctx = lambda: job.last.ctx
+    else:
+        job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=a_lo, has_low_halo=bool(halo),
+                          max_label=max_label, features=feats, group=(dist.group.WORLD if n > 1 else None),
+                          device=local_rank)
+        last_ctx = lambda: ctx
 
     def barrier():
         if n > 1:
@@ -148,10 +158,10 @@ def main():
         job.step()
         job.finish()
         torch.cuda.synchronize()
-        t = ctx.timing()
+        t = last_ctx().timing()
         sweep_ms.append(t["ms_sweep"])
         adj_ms.append(t["ms_adjacency"])
-    bytes_read = ctx.timing()["bytes_read"]
+    bytes_read = last_ctx().timing()["bytes_read"]
 
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
     if n > 1:
@@ -181,7 +191,7 @@ def main():
             "config": {"workload": "%s: %dx%dx%d %s, %d seeds (%d labels present), features=0x%x, Z-slab x%d"
                                    % (cfg["name"], dims[0], dims[1], dims[2], dtype.name, cfg["n_cells"],
                                       labels_present, feats, n),
-                       "voxels_per_gpu": int(nvox / n), "label_dtype": dtype.name,
+                       "voxels_per_gpu": int(nvox / n), "label_dtype": dtype.name, "steps_in_flight": depth,
                        "pct_hbm_roofline": round(100.0 * achieved / HBM_PEAK_GBS, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

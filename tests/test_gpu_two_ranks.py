@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None, pair_slots=0):
+def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None, pair_slots=0, depth=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -31,10 +31,16 @@ def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None
         vol, max_label = dev.synth_slab(ctx, dims, dtype, n_cells, seed, lo - halo, hi, device=0)
         if pair_slots and rank == 1:    # one rank starts with a table far too small: sizes must be agreed on
             ctx.set_option(_capi.OPT_PAIR_SLOTS, pair_slots)
-        job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=lo, has_low_halo=bool(halo), max_label=max_label,
-                          features=_capi.F_ALL, group=dist.group.WORLD, device=0, exchange_capacity=capacity)
-        job.step()
-        job.step()                      # a second step must give the same answer (tables self-clean)
+        if depth > 1:                   # two steps in flight on two streams / contexts
+            job = tad.PipelinedSlabJob(vol, dtype.itemsize, a_origin=lo, has_low_halo=bool(halo), max_label=max_label,
+                                       features=_capi.F_ALL, group=dist.group.WORLD, device=0, depth=depth)
+            for _ in range(3):
+                job.step()
+        else:
+            job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=lo, has_low_halo=bool(halo), max_label=max_label,
+                              features=_capi.F_ALL, group=dist.group.WORLD, device=0, exchange_capacity=capacity)
+            job.step()
+            job.step()                  # a second step must give the same answer (tables self-clean)
         got = job.result_arrays()
         whole = synth.voronoi_labels(dims, n_cells, seed, dtype)
         want = onepass_c.extract(whole, max_label=max_label)
@@ -51,18 +57,19 @@ def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dims,n_cells,dtype_name,capacity,pair_slots", [
-    ((37, 40, 264), 50, "uint32", None, 0),
-    ((20, 24, 520), 30, "uint16", None, 0),
-    ((37, 40, 264), 50, "uint32", 8, 0),        # exchange blocks too small: verdict -> re-size -> redo
-    ((37, 40, 264), 50, "uint32", None, 6),     # rank 1 starts with a 64-slot table: grown and agreed on
+@pytest.mark.parametrize("dims,n_cells,dtype_name,capacity,pair_slots,depth", [
+    ((37, 40, 264), 50, "uint32", None, 0, 1),
+    ((20, 24, 520), 30, "uint16", None, 0, 1),
+    ((37, 40, 264), 50, "uint32", 8, 0, 1),        # exchange blocks too small: verdict -> re-size -> redo
+    ((37, 40, 264), 50, "uint32", None, 6, 1),     # rank 1 starts with a 64-slot table: grown and agreed on
+    ((37, 40, 264), 50, "uint32", None, 0, 2),     # PipelinedSlabJob: steps alternate between two streams
 ])
-def test_two_ranks_on_one_gpu_match_unsharded(dims, n_cells, dtype_name, capacity, pair_slots):
+def test_two_ranks_on_one_gpu_match_unsharded(dims, n_cells, dtype_name, capacity, pair_slots, depth):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29800 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, n_cells, 61, dtype_name, q, capacity, pair_slots))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, n_cells, 61, dtype_name, q, capacity, pair_slots, depth))
              for r in range(world)]
     for p in procs:
         p.start()

@@ -96,9 +96,12 @@ class SlabJob(object):
     """
 
     def __init__(self, ctx, vol_tensor, itemsize, a_origin, has_low_halo, max_label, features,
-                 group=None, device=0, exchange_capacity=None):
+                 group=None, device=0, exchange_capacity=None, stream=None):
         import torch
         self.ctx, self.vol, self.group = ctx, vol_tensor, group
+        self.stream = stream                    # torch.cuda.Stream all of this job's work is ordered on, or None
+        if stream is not None:
+            ctx.set_stream(stream.cuda_stream)
         self.has_low_halo = bool(has_low_halo)
         self.max_label, self.features = int(max_label), features
         dev = "cuda:%d" % device
@@ -152,7 +155,22 @@ class SlabJob(object):
             self._recv = torch.empty((world * words,), dtype=torch.int64, device=self.sums.device)
         return world
 
+    def _on_stream(self):
+        import contextlib
+        return self._torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
     def step(self):
+        with self._on_stream():
+            self._step()
+
+    def finish(self):
+        """COLLECTIVE (every rank of the group must call it, like step()): read the verdict of the
+        last step; re-size and redo it when an exchange block or an adjacency table was too small
+        anywhere.  The result getters call it, so they are collective too until it has run."""
+        with self._on_stream():
+            self._finish()
+
+    def _step(self):
         import torch.distributed as dist
         torch = self._torch
         self.ctx.extract(self.features, self.max_label)
@@ -171,12 +189,9 @@ class SlabJob(object):
             if dist.get_backend(self.group) != "nccl":
                 torch.cuda.synchronize()
             self.ctx.adjacency_merge_blocks(self._recv.data_ptr(), world, self._cap)
-            self._unverified = True
+        self._unverified = True
 
-    def finish(self):
-        """COLLECTIVE (every rank of the group must call it, like step()): read the verdict of the
-        last step; re-size and redo it when an exchange block or an adjacency table was too small
-        anywhere.  The result getters call it, so they are collective too until it has run."""
+    def _finish(self):
         if not self._unverified:
             return
         import torch.distributed as dist
@@ -185,22 +200,27 @@ class SlabJob(object):
         for attempt in range(6):
             status = 0
             try:
-                self.ctx.adjacency_size()
+                self.ctx.adjacency_size()                  # drains this job's stream, validates the flags
             except _capi.TissueScanError as e:
-                if e.code != _capi.TA_ECAPACITY:
+                if e.code not in (_capi.TA_ECAPACITY, _capi.TA_ERANGE):
                     raise
-                status = 1
+                status = 1 if e.code == _capi.TA_ECAPACITY else 2
             t = torch.tensor([status], dtype=torch.int64, device=self.sums.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-            if int(t.item()) == 0:
+            status = int(t.item())
+            if status == 0:
                 self._unverified = False
                 return
+            if status == 2:                                # same exception on every rank
+                self._unverified = False
+                raise _capi.TissueScanError(_capi.TA_ERANGE, "a rank's slab holds a label above max_label=%d"
+                                            % self.max_label)
             self.redo_count += 1
             self._cap = None
             self._send = self._recv = None
             if attempt > 0:                                # re-measured blocks were not enough: grow the tables
                 self.ctx.set_option(_capi.OPT_PAIR_SLOTS, self.ctx.get_option(_capi.OPT_PAIR_SLOTS) + 2)
-            self.step()
+            self._step()
         raise RuntimeError("adjacency exchange still overflows after %d attempts" % 6)
 
     def result_counts(self):
@@ -222,3 +242,56 @@ class SlabJob(object):
             faces = np.zeros((0, 3), dtype=np.uint64)
         out.update(pair_lo=lo, pair_hi=hi, pair_faces=faces)
         return out
+
+
+class PipelinedSlabJob(object):
+    """`depth` SlabJobs over the SAME resident slab, each with its own C-ABI context, accumulators,
+    exchange buffers and HIP stream, used round-robin: step i's reduce / adjacency exchange (ordered
+    on stream i % depth) overlaps step i+1's sweep (on the next stream), the way a time series of
+    volumes would be processed.  Every step still does all of its work; finish() (collective) waits
+    for and validates every step in flight, in issue order."""
+
+    def __init__(self, vol_tensor, itemsize, a_origin, has_low_halo, max_label, features, group=None,
+                 device=0, depth=2, tile_planes=0):
+        import torch
+        from . import _capi
+        torch.cuda.synchronize(device)            # the slab was written on another stream
+        self.jobs = []
+        for _ in range(max(1, int(depth))):
+            stream = torch.cuda.Stream(device=device)
+            ctx = _capi.Context(device)
+            if tile_planes:
+                ctx.set_option(_capi.OPT_TILE_PLANES, tile_planes)
+            with torch.cuda.stream(stream):
+                self.jobs.append(SlabJob(ctx, vol_tensor, itemsize, a_origin, has_low_halo, max_label, features,
+                                         group=group, device=device, stream=stream))
+        self._issued = 0
+
+    @property
+    def last(self):
+        """The SlabJob that ran the most recent step (its ctx holds that step's adjacency)."""
+        return self.jobs[(self._issued - 1) % len(self.jobs)]
+
+    def owned_view(self):
+        return self.jobs[0].owned_view()
+
+    def step(self):
+        self.jobs[self._issued % len(self.jobs)].step()
+        self._issued += 1
+
+    def finish(self):
+        n = len(self.jobs)
+        for k in range(max(0, self._issued - n), self._issued):     # oldest step in flight first
+            self.jobs[k % n].finish()
+
+    def result_counts(self):
+        self.finish()
+        return self.last.result_counts()
+
+    def result_arrays(self):
+        self.finish()
+        return self.last.result_arrays()
+
+    def close(self):
+        for j in self.jobs:
+            j.ctx.close()
