@@ -11,12 +11,14 @@ ap.add_argument("--tp", type=int, nargs="*", default=[64])
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--dims", type=int, nargs=3, default=None)
 ap.add_argument("--cells", type=int, default=None)
+ap.add_argument("--impl", type=int, default=0)
 args = ap.parse_args()
 c = synth.CONFIGS[args.config]
 dims = tuple(args.dims) if args.dims else c["dims"]
 dtype = np.dtype(c["dtype"])
 ncell = args.cells or c["n_cells"]
 ctx = dev.torch_context(0)
+ctx.set_option(_capi.OPT_IMPL, args.impl)
 t0 = time.time()
 vol, max_label = dev.synth_slab(ctx, dims, dtype, ncell, c["seed"])
 torch.cuda.synchronize()

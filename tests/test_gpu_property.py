@@ -31,16 +31,17 @@ def volumes(draw):
     v = np.ascontiguousarray(v[:shape[0], :shape[1], :shape[2]])
     order = draw(st.sampled_from(["C", "F"]))
     tile_planes = draw(st.sampled_from([1, 2, 5, 32]))
-    return (np.asfortranarray(v) if order == "F" else v), tile_planes
+    impl = draw(st.sampled_from([0, 2]))
+    return (np.asfortranarray(v) if order == "F" else v), tile_planes, impl
 
 
 @settings(max_examples=60, deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture, HealthCheck.too_slow])
 @given(case=volumes())
 def test_random_volumes_match_the_oracle(gpu_ctx, case):
-    vol, tile_planes = case
+    vol, tile_planes, impl = case
     want = onepass_c.extract(np.ascontiguousarray(vol))
-    got = extract_volume(vol, context=gpu_ctx, impl=0, tile_planes=tile_planes).as_arrays()
-    assert_same_accumulators(got, want, "shape=%s dtype=%s tp=%d" % (vol.shape, vol.dtype, tile_planes))
+    got = extract_volume(vol, context=gpu_ctx, impl=impl, tile_planes=tile_planes).as_arrays()
+    assert_same_accumulators(got, want, "shape=%s dtype=%s tp=%d impl=%d" % (vol.shape, vol.dtype, tile_planes, impl))
 
 
 def test_refresh_after_in_place_edit():

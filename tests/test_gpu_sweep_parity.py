@@ -32,7 +32,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("impl", [1, 0], ids=["naive", "fused"])
+@pytest.mark.parametrize("impl", [1, 0, 2], ids=["naive", "fused", "split"])
 @pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
 def test_accumulators_match_oracle(gpu_ctx, name, make, impl):
     vol = make()
@@ -41,21 +41,23 @@ def test_accumulators_match_oracle(gpu_ctx, name, make, impl):
     assert_same_accumulators(got, want, "%s impl=%d" % (name, impl))
 
 
+@pytest.mark.parametrize("impl", [0, 2], ids=["fused", "split"])
 @pytest.mark.parametrize("tile_planes", [1, 2, 5, 64])
-def test_tile_planes_do_not_change_results(gpu_ctx, tile_planes):
+def test_tile_planes_do_not_change_results(gpu_ctx, tile_planes, impl):
     vol = voronoi((23, 40, 300), 50, 11, np.uint32)
     want = onepass_c.extract(vol)
-    got = run(gpu_ctx, vol, 0, tile_planes=tile_planes)
-    assert_same_accumulators(got, want, "tile_planes=%d" % tile_planes)
+    got = run(gpu_ctx, vol, impl, tile_planes=tile_planes)
+    assert_same_accumulators(got, want, "tile_planes=%d impl=%d" % (tile_planes, impl))
 
 
 @pytest.mark.parametrize("features", [_capi.F_VOLUME | _capi.F_BBOX | _capi.F_MOMENT1,
                                       _capi.F_VOLUME | _capi.F_BBOX | _capi.F_MOMENT1 | _capi.F_ADJACENCY,
                                       _capi.F_VOLUME | _capi.F_BBOX | _capi.F_MOMENT1 | _capi.F_MOMENT2])
-def test_feature_subsets(gpu_ctx, features):
+@pytest.mark.parametrize("impl", [0, 2], ids=["fused", "split"])
+def test_feature_subsets(gpu_ctx, features, impl):
     vol = voronoi((20, 33, 260), 40, 12, np.uint32)
     want = onepass_c.extract(vol)
-    got = run(gpu_ctx, vol, 0, features=features)
+    got = run(gpu_ctx, vol, impl, features=features)
     for k in ("count", "bbox", "sum1"):
         assert np.array_equal(got[k], want[k]), k
     if features & _capi.F_MOMENT2:
@@ -82,3 +84,15 @@ def test_label_above_max_label_is_reported(gpu_ctx):
     with pytest.raises(_capi.TissueScanError) as e:
         run(gpu_ctx, vol, 0, max_label=int(vol.max()) - 1)
     assert e.value.code == _capi.TA_ERANGE
+
+
+def test_split_path_falls_back_on_noise(gpu_ctx):
+    """Per-voxel noise has far more events than a record region holds: the split path must notice
+    and hand the volume to the fused sweep, silently and exactly."""
+    rng = np.random.default_rng(15)
+    vol = rng.integers(1, 50, size=(40, 16, 256)).astype(np.uint32)
+    want = onepass_c.extract(vol)
+    got = run(gpu_ctx, vol, 2)
+    assert_same_accumulators(got, want, "noise through impl=2")
+    got = run(gpu_ctx, voronoi((40, 16, 256), 20, 16, np.uint32), 2)      # and a tissue volume afterwards
+    assert_same_accumulators(got, onepass_c.extract(voronoi((40, 16, 256), 20, 16, np.uint32)), "tissue after noise")

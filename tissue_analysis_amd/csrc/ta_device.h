@@ -15,13 +15,13 @@ constexpr int NBOX = 6;                             // min0,min1,min2,-max0,-max
 
 // flag words written by kernels, read back by the host after the stream drains
 enum { FLAG_RANGE = 0, FLAG_PAIR_OVERFLOW = 1, FLAG_LDS_LABEL_SPILL = 2, FLAG_LDS_PAIR_SPILL = 3,
-       FLAG_EXCHANGE_OVERFLOW = 4, NFLAGS = 16 };
+       FLAG_EXCHANGE_OVERFLOW = 4, FLAG_REGION_OVERFLOW = 5, NFLAGS = 16 };
 
 // Exchange block of one rank (multi-GPU adjacency merge), u64 words:
 //   [0] pair count n (may exceed the capacity: receivers flag the overflow)   [1] status bits
 //   [2 .. 2+cap) keys, EMPTY_KEY padded        [2+cap .. 2+4*cap) faces[cap][3]
 constexpr int XHDR = 2;
-constexpr uint64_t XSTATUS_RANGE = 1, XSTATUS_PAIR_OVERFLOW = 2;
+constexpr uint64_t XSTATUS_RANGE = 1, XSTATUS_PAIR_OVERFLOW = 2, XSTATUS_REGION_OVERFLOW = 4;
 
 struct PairTable {           // device-global open-addressing hash: key = lo<<32|hi
     uint64_t* keys;          // [cap], EMPTY_KEY when free
@@ -41,6 +41,15 @@ struct SweepArgs {
     int32_t* boxes;          // [max_label+1][NBOX]
     PairTable pairs;
     uint32_t* flags;         // [NFLAGS]
+};
+
+// split path (emit kernel -> record regions in HBM -> reduce kernel); one region per wave tile
+struct SplitArgs {
+    SweepArgs a;
+    uint64_t* frec;          // [wave tiles][fcap] face records {voxel, neighbour | axis << 30}
+    uint64_t* rrec;          // [wave tiles][rcap] run records  {label, c | b << 10 | a0 << 14 | n << 20}
+    uint32_t* rhdr;          // [wave tiles][4]   faces, runs, uniform label (or a sentinel), planes - 1
+    uint32_t fcap, rcap;
 };
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
