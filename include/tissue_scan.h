@@ -149,6 +149,20 @@ TA_API int ta_adjacency_export(ta_ctx* ctx, void* keys_dst_dev, void* faces_dst_
  * RCCL) into this context's adjacency: sums face counts of equal keys. */
 TA_API int ta_adjacency_merge(ta_ctx* ctx, const void* keys_dev, const void* faces_dev, int64_t npairs);
 
+/* ---- label lookup-table sweeps over the resident volume -------------------
+ * ta_volume_relabel: in place, v -> lut[v] for v < lut_len, other voxels unchanged.  Replaces the
+ * per-label bounding-box loops of fuse_labels_in_image / remove_labels_from_image (SIA:1114-1165).
+ * lut is a HOST array; with a uint16 volume every entry must be <= 65535.  Invalidates the last
+ * extraction.  Not allowed on a slab with a halo plane (the neighbour owns that plane).
+ * ta_volume_get: copy the resident volume back to the host, same dense layout as it was set with.
+ * ta_volume_map: out[p] = lut[V[p]] (fill for V[p] >= lut_len) into a HOST image of out_itemsize
+ * (1, 2, 4 or 8) byte words, same layout as the volume; lut and fill are words of that size
+ * (PropertySpatialImage.create_property_image, PSI:207-221). */
+TA_API int ta_volume_relabel(ta_ctx* ctx, const uint32_t* lut, uint32_t lut_len);
+TA_API int ta_volume_get(ta_ctx* ctx, void* host_dst);
+TA_API int ta_volume_map(ta_ctx* ctx, const void* lut, uint32_t lut_len, const void* fill, int out_itemsize,
+                         void* host_dst);
+
 /* ---- stream-ordered adjacency exchange (no host round trip) ------------------
  * One exchange block per rank, uint64 words, TA_EXCHANGE_WORDS(capacity) long:
  *   [0] pair count (may exceed capacity)  [1] status bits  [2..2+cap) keys, ~0 padded

@@ -433,6 +433,60 @@ class OracleSIA(object):
         return tuple(slice(a, b) for a, b in zip(starts, stops))
 
 
+    # -- image mutation (SIA:1114-1176), as written: per-label bounding-box crops, image edited in place;
+    # the bounding boxes are the ones cached at construction (the reference never refreshes them)
+    def fuse_labels_in_image(self, labels, verbose=False):  # SIA:1114-1136
+        assert isinstance(labels, list) and len(labels) >= 2
+        assert self._background not in labels
+        min_lab = min(labels)
+        labels.remove(min_lab)
+        for label in labels:
+            bbox = self.boundingbox(label)
+            if bbox is None:
+                continue                                     # "No boundingbox found ..., skipping"
+            crop = np.asarray(self.image)[bbox]
+            xyz = np.where(crop == label)
+            np.asarray(self.image)[tuple(x + b.start for x, b in zip(xyz, bbox))] = min_lab
+        return None
+
+    def remove_labels_from_image(self, labels, erase_value=0, verbose=False):  # SIA:1138-1165
+        if isinstance(labels, (int, np.integer)):
+            labels = [labels]
+        try:
+            labels.remove(self._background)
+        except ValueError:
+            pass
+        for label in labels:
+            bbox = self.boundingbox(label)
+            if bbox is None:
+                continue
+            crop = np.asarray(self.image)[bbox]
+            xyz = np.where(crop == label)
+            np.asarray(self.image)[tuple(x + b.start for x, b in zip(xyz, bbox))] = erase_value
+        self._ignoredlabels.update([erase_value])
+        for label in labels:
+            self._ignoredlabels.discard(label)
+
+    def remove_stack_margin_labels_from_image(self, erase_value=0, voxel_distance_from_margin=5, verbose=False):
+        self.remove_labels_from_image(self.labels_at_stack_margins(voxel_distance_from_margin), erase_value, verbose)
+
+
+def property_image(image, property_dict, background, dtype=np.uint16):
+    """PropertySpatialImage.create_property_image (PSI:207-221): every label of the image without a
+    value gets the background id, so does the background itself; the per-voxel lookup is then cast."""
+    values = dict(property_dict)
+    for l in np.unique(image):
+        if int(l) not in values:
+            values[int(l)] = background
+    values[background] = background
+    img = np.asarray(image)
+    out = np.empty(img.shape, dtype=np.float64)
+    for l in np.unique(img):
+        out[img == l] = values[int(l)]
+    with np.errstate(invalid="ignore"):
+        return out.astype(dtype)
+
+
 def full_feature_set(image, voxelsize, background=1, with_inertia=True, with_walls=True,
                      labels=None):
     """The call sequence of temporal_graph_from_image._graph_from_image (TGI:104-191) on one

@@ -206,3 +206,19 @@ def test_worst_case_noise_volume_spills_correctly(gpu_ctx):
     got = extract_volume(vol, context=gpu_ctx, impl=0).as_arrays()
     assert_same_accumulators(got, want, "noise")
     assert gpu_ctx.debug_counters()["label_spills"] > 0
+
+
+def test_graph_from_image_end_to_end_on_gpu():
+    """The reference's documented workflow (TGI:260-284) from a raw labelled image: one GPU sweep,
+    then host-side table assembly; compared with the oracle's restatement on the same image."""
+    from oracle import graph_oracle
+    from tissue_analysis_amd import graph_from_image, property_graph_to_dataframe
+    from graph_compare import compare_graph
+    props = ['boundingbox', 'volume', 'barycenter', 'L1', 'border', 'inertia_axis', 'wall_surface', 'epidermis_surface']
+    vol = voronoi((48, 40, 72), 60, 41, np.uint16)
+    img = SpatialImage(vol, voxelsize=synth.PARITY_VOXELSIZE)
+    g = graph_from_image(img, spatio_temporal_properties=list(props), min_contact_area=2.0)
+    want = graph_oracle.graph_tables(vol, None, 1, list(props), True, True, 2.0, voxelsize=synth.PARITY_VOXELSIZE)
+    assert g.nb_vertices() > 10 and g.nb_edges() > 10
+    compare_graph(g, want)
+    assert len(property_graph_to_dataframe(g, 'vertex')) == g.nb_vertices()

@@ -1,0 +1,79 @@
+"""`graph_from_image` on CPU: host logic only -- the integer accumulators are
+injected as the GPU would produce them -- against the oracle's restatement of TGI:77-244."""
+import numpy as np
+import pytest
+
+from oracle import graph_oracle, onepass, sia_oracle
+from oracle.sia_oracle import OracleSIA
+from tissue_analysis_amd import DICT, Extraction, SpatialImage, SpatialImageAnalysis3D, synth
+from tissue_analysis_amd.graph_from_image import (availables_properties, availables_spatial_properties,
+                                                  generate_graph_topology, graph_from_image,
+                                                  property_graph_to_dataframe, spatio_temporal_properties3D)
+
+from graph_compare import compare_graph
+from helpers import voronoi
+
+VS = synth.PARITY_VOXELSIZE
+ALL = ['boundingbox', 'volume', 'barycenter', 'L1', 'border', 'inertia_axis', 'wall_surface', 'epidermis_surface']
+
+
+def analysis(vol):
+    x = Extraction.from_arrays(vol.shape, onepass.extract(vol))
+    return SpatialImageAnalysis3D(SpatialImage(vol, voxelsize=VS), ignoredlabels=0, return_type=DICT, background=1,
+                                  extraction=x)
+
+
+def oracle_analysis(vol):
+    return OracleSIA(vol, ignoredlabels=0, return_type=sia_oracle.DICT, background=1, voxelsize=VS)
+
+
+@pytest.mark.parametrize("props,real,margins,min_area", [
+    (ALL, True, True, None),
+    (ALL, False, False, None),
+    (['volume', 'inertia_axis', 'wall_surface'], True, False, 6.0),     # no barycentre: inertia in voxel units
+    (spatio_temporal_properties3D, True, True, None),                   # the default list: the *_area names compute nothing
+])
+def test_graph_matches_the_reference_restatement(props, real, margins, min_area):
+    vol = voronoi((40, 36, 44), 40, 31, np.uint16)
+    g = graph_from_image(analysis(vol), labels=None, background=1, spatio_temporal_properties=list(props),
+                         property_as_real=real, ignore_cells_at_stack_margins=margins, min_contact_area=min_area)
+    want = graph_oracle.graph_tables(oracle_analysis(vol), None, 1, list(props), real, margins, min_area)
+    assert g.nb_vertices() > 5 and g.nb_edges() > 5
+    compare_graph(g, want)
+
+
+def test_label_subset_ignores_the_rest():
+    vol = voronoi((40, 36, 44), 40, 32, np.uint16)
+    sia = analysis(vol)
+    keep = [l for l in sia.labels() if l != 1][3:15]
+    g = graph_from_image(sia, labels=list(keep), spatio_temporal_properties=list(ALL), ignore_cells_at_stack_margins=False)
+    want = graph_oracle.graph_tables(oracle_analysis(vol), list(keep), 1, list(ALL), True, False, None)
+    compare_graph(g, want)
+    assert sorted(g.vertices()) == sorted(keep)
+
+
+def test_advertised_names_and_topology_helper():
+    assert availables_properties() == sorted(availables_spatial_properties())
+    assert 'wall_median' in availables_properties() and 'wall_median' not in spatio_temporal_properties3D
+    g, l2v, edges = generate_graph_topology([2, 3, 5], {2: [3, 9], 3: [2, 5], 5: [3], 9: [2]})
+    assert l2v == {2: 2, 3: 3, 5: 5} and sorted(edges) == [(2, 3), (3, 5)]
+    assert sorted(g.neighbors(3)) == [2, 5]
+    with pytest.raises(NotImplementedError):
+        graph_from_image(analysis(voronoi((12, 12, 12), 4, 33, np.uint16)), spatio_temporal_properties=['wall_median'])
+
+
+def test_dataframe_export():
+    vol = voronoi((40, 36, 44), 40, 34, np.uint16)
+    g = graph_from_image(analysis(vol), spatio_temporal_properties=list(ALL), ignore_cells_at_stack_margins=False)
+    dv = property_graph_to_dataframe(g, 'vertex')
+    assert sorted(dv.index) == sorted(g.vertices())
+    assert {'label', 'volume', 'L1', 'border', 'barycenter_x', 'barycenter_y', 'barycenter_z'} <= set(dv.columns)
+    assert 'inertia_axis' not in dv.columns                             # non-scalar properties are skipped
+    l = dv.index[0]
+    assert dv.loc[l, 'volume'] == g.vertex_property('volume')[l]
+    np.testing.assert_allclose([dv.loc[l, 'barycenter_' + a] for a in 'xyz'], g.vertex_property('barycenter')[l])
+    de = property_graph_to_dataframe(g, 'edge')
+    assert len(de) == g.nb_edges() and 'wall_surface' in de.columns
+    some = sorted(g.vertices())[:6]
+    de2 = property_graph_to_dataframe(g, 'edge', labels=some)
+    assert all(set(g.edge_vertices(e)) <= set(some) for e in de2.index)

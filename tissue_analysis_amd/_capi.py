@@ -24,7 +24,8 @@ OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS = 1, 2, 3
 SYMBOLS = (
     "ta_version", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_get_option", "ta_ctx_synchronize", "ta_volume_set",
-    "ta_volume_set_device", "ta_volume_max_label", "ta_extract", "ta_get_labels",
+    "ta_volume_set_device", "ta_volume_max_label", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
+    "ta_extract", "ta_get_labels",
     "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_debug_counters", "ta_bind_accumulators",
     "ta_accumulators_device", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge",
     "ta_adjacency_pack", "ta_adjacency_merge_blocks", "ta_synth_voronoi",
@@ -72,6 +73,9 @@ def load():
         "ta_volume_set": (ci, [vp, vp, ci, P(i64), P(i64)]),
         "ta_volume_set_device": (ci, [vp, vp, ci, P(i64), i64, ci]),
         "ta_volume_max_label": (ci, [vp, P(u32)]),
+        "ta_volume_relabel": (ci, [vp, vp, u32]),
+        "ta_volume_get": (ci, [vp, vp]),
+        "ta_volume_map": (ci, [vp, vp, u32, vp, ci, vp]),
         "ta_extract": (ci, [vp, u32, u32]),
         "ta_get_labels": (ci, [vp, vp, vp, vp, vp]),
         "ta_adjacency_size": (ci, [vp, P(i64)]),
@@ -190,6 +194,34 @@ class Context(object):
             a = np.ascontiguousarray(a)
         _check(self._lib.ta_volume_set(self._h, ctypes.c_void_p(a.ctypes.data), a.dtype.itemsize,
                                        _i64x3(a.shape), _i64x3(a.strides)))
+
+    def relabel(self, lut):
+        """In place on the resident volume: v -> lut[v] for v < len(lut) (host uint32 table)."""
+        lut = np.ascontiguousarray(lut, dtype=np.uint32)
+        _check(self._lib.ta_volume_relabel(self._h, ctypes.c_void_p(lut.ctypes.data), int(lut.size)))
+
+    def get_volume(self, out):
+        """Copy the resident volume into `out`, which must have the dtype, shape and dense layout
+        of the array given to set_volume()."""
+        if not (isinstance(out, np.ndarray) and _dense_permuted(out) and out.flags.writeable):
+            raise ValueError("get_volume needs a writeable dense (possibly axis-permuted) ndarray")
+        _check(self._lib.ta_volume_get(self._h, ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+    def map_labels(self, lut, fill, like):
+        """out[p] = lut[V[p]] (fill beyond the table): `lut` is a 1-D array of a 1/2/4/8-byte dtype;
+        the result has that dtype and the shape and layout of `like` (the array given to set_volume)."""
+        lut = np.ascontiguousarray(lut)
+        if lut.dtype.itemsize not in (1, 2, 4, 8):
+            raise TypeError("lookup tables of %s are not supported" % lut.dtype)
+        out = np.empty_like(like, dtype=lut.dtype)            # keeps the memory order of `like`
+        if not _dense_permuted(out):
+            raise ValueError("map_labels needs a dense (possibly axis-permuted) volume")
+        fillv = np.array([fill]).astype(lut.dtype)
+        _check(self._lib.ta_volume_map(self._h, ctypes.c_void_p(lut.ctypes.data), int(lut.size),
+                                       ctypes.c_void_p(fillv.ctypes.data), int(lut.dtype.itemsize),
+                                       ctypes.c_void_p(out.ctypes.data)))
+        return out
 
     def set_volume_device(self, dev_ptr, itemsize, buf_dims, a0_origin=0, has_low_halo=False, keep=None):
         _check(self._lib.ta_volume_set_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(itemsize),

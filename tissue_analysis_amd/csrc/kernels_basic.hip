@@ -275,6 +275,84 @@ void launch_pairs_clear(hipStream_t s, const PairTable& pt) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Label lookup-table sweeps: v -> lut[v].  HBM-bound gathers: the table (4 bytes
+// per label, ~200 KB at 50k labels) lives in L2 / the vector L1, neighbouring voxels mostly share a
+// label so a wave's gather touches a handful of cache lines.
+// relabel_kernel: in place, 16-byte loads and stores (SIA:1114-1165 fuse / remove, done per label
+// with bounding-box crops in the reference).  map_kernel: to an output image of another word size
+// (PSI:207-221 create_property_image), labels beyond the table get `fill`.
+template <typename T>
+__global__ void __launch_bounds__(256) relabel_kernel(T* vol, uint64_t n, uint64_t nvec,
+                                                      const uint32_t* __restrict__ lut, uint32_t lut_len) {
+    constexpr int PER = 16 / (int)sizeof(T);
+    uint4* v4 = reinterpret_cast<uint4*>(vol);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        uint4 x = v4[i];
+        uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (sizeof(T) == 4) {
+                if (w[k] < lut_len) w[k] = lut[w[k]];
+            } else {
+                uint32_t lo = w[k] & 0xffffu, hi = w[k] >> 16;
+                if (lo < lut_len) lo = lut[lo];
+                if (hi < lut_len) hi = lut[hi];
+                w[k] = (lo & 0xffffu) | (hi << 16);
+            }
+        }
+        v4[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    // tail: fewer than PER voxels, or the whole volume when the buffer is not 16-byte aligned (nvec = 0)
+    for (uint64_t t = nvec * PER + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
+         t += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = vol[t];
+        if (v < lut_len) vol[t] = (T)lut[v];
+    }
+}
+
+void launch_relabel(hipStream_t s, void* vol, int itemsize, uint64_t n, const uint32_t* lut, uint32_t lut_len) {
+    if (n == 0) return;
+    const uint64_t nvec = ((uintptr_t)vol & 15) ? 0 : n / (16 / itemsize);
+    uint64_t blocks = ((nvec ? nvec : n) + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 16384) blocks = 16384;
+    if (itemsize == 2) hipLaunchKernelGGL(relabel_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (uint16_t*)vol, n, nvec, lut, lut_len);
+    else               hipLaunchKernelGGL(relabel_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)vol, n, nvec, lut, lut_len);
+}
+
+template <typename TI, typename TO>
+__global__ void __launch_bounds__(256) map_kernel(const TI* __restrict__ vol, TO* __restrict__ out, uint64_t n,
+                                                  const TO* __restrict__ lut, uint32_t lut_len, TO fill) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t v = vol[i];
+        out[i] = v < lut_len ? lut[v] : fill;
+    }
+}
+
+template <typename TI>
+static void launch_map_t(hipStream_t s, const void* vol, void* out, int out_itemsize, uint64_t n, const void* lut,
+                         uint32_t lut_len, uint64_t fill) {
+    uint64_t blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    const dim3 g((unsigned)blocks), b(256);
+    switch (out_itemsize) {
+        case 1: hipLaunchKernelGGL((map_kernel<TI, uint8_t>), g, b, 0, s, (const TI*)vol, (uint8_t*)out, n, (const uint8_t*)lut, lut_len, (uint8_t)fill); break;
+        case 2: hipLaunchKernelGGL((map_kernel<TI, uint16_t>), g, b, 0, s, (const TI*)vol, (uint16_t*)out, n, (const uint16_t*)lut, lut_len, (uint16_t)fill); break;
+        case 4: hipLaunchKernelGGL((map_kernel<TI, uint32_t>), g, b, 0, s, (const TI*)vol, (uint32_t*)out, n, (const uint32_t*)lut, lut_len, (uint32_t)fill); break;
+        default: hipLaunchKernelGGL((map_kernel<TI, uint64_t>), g, b, 0, s, (const TI*)vol, (uint64_t*)out, n, (const uint64_t*)lut, lut_len, (uint64_t)fill); break;
+    }
+}
+
+void launch_map(hipStream_t s, const void* vol, int itemsize, void* out, int out_itemsize, uint64_t n,
+                const void* lut, uint32_t lut_len, uint64_t fill) {
+    if (n == 0) return;
+    if (itemsize == 2) launch_map_t<uint16_t>(s, vol, out, out_itemsize, n, lut, lut_len, fill);
+    else               launch_map_t<uint32_t>(s, vol, out, out_itemsize, n, lut, lut_len, fill);
+}
+
+// ------------------------------------------------------------------------------------------
 // Synthetic jittered-grid Voronoi tissue (tissue_analysis_amd/synth.py is the definition).
 template <typename T>
 __global__ void __launch_bounds__(256) synth_kernel(T* out, int64_t d0, int64_t d1, int64_t d2,

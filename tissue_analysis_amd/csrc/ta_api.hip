@@ -397,6 +397,70 @@ TA_API int ta_volume_set_device(ta_ctx* c, const void* dev_ptr, int itemsize, co
     return TA_OK;
 }
 
+TA_API int ta_volume_relabel(ta_ctx* c, const uint32_t* lut, uint32_t lut_len) {
+    if (!c || (!lut && lut_len)) return fail(TA_EINVAL, "NULL argument");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    if (c->first_owned) return fail(TA_EINVAL, "cannot relabel a slab that carries a halo plane");
+    if (c->itemsize == 2)
+        for (uint32_t i = 0; i < lut_len; ++i)
+            if (lut[i] > 0xFFFFu) return fail(TA_ERANGE, "lut[%u]=%u does not fit the uint16 volume", i, lut[i]);
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    if (lut_len == 0) return TA_OK;
+    DevBuf d;
+    if ((rc = d.reserve((uint64_t)lut_len * 4)) != TA_OK) return rc;
+    hipError_t e = hipMemcpyAsync(d.p, lut, (uint64_t)lut_len * 4, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        ta::launch_relabel(c->stream, const_cast<void*>(c->vol), c->itemsize,
+                           (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2], (const uint32_t*)d.p, lut_len);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    d.release();
+    if (e != hipSuccess) return fail(TA_EHIP, "relabel: %s", hipGetErrorString(e));
+    c->extracted = c->checked = false;
+    c->split_failed = false;
+    return TA_OK;
+}
+
+TA_API int ta_volume_get(ta_ctx* c, void* host_dst) {
+    if (!c || !host_dst) return fail(TA_EINVAL, "NULL argument");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t bytes = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2] * c->itemsize;
+    TA_HIP(hipMemcpyAsync(host_dst, c->vol, bytes, hipMemcpyDeviceToHost, c->stream));
+    TA_HIP(hipStreamSynchronize(c->stream));
+    return TA_OK;
+}
+
+TA_API int ta_volume_map(ta_ctx* c, const void* lut, uint32_t lut_len, const void* fill, int out_itemsize,
+                         void* host_dst) {
+    if (!c || !fill || !host_dst || (!lut && lut_len)) return fail(TA_EINVAL, "NULL argument");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    if (out_itemsize != 1 && out_itemsize != 2 && out_itemsize != 4 && out_itemsize != 8)
+        return fail(TA_EINVAL, "out_itemsize must be 1, 2, 4 or 8");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t n = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2];
+    uint64_t fillw = 0;
+    memcpy(&fillw, fill, (size_t)out_itemsize);
+    DevBuf dl, dout;
+    if ((rc = dl.reserve((uint64_t)lut_len * out_itemsize + 8)) != TA_OK) return rc;
+    if ((rc = dout.reserve(n * out_itemsize)) != TA_OK) { dl.release(); return rc; }
+    hipError_t e = hipSuccess;
+    if (lut_len) e = hipMemcpyAsync(dl.p, lut, (uint64_t)lut_len * out_itemsize, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) {
+        ta::launch_map(c->stream, c->vol, c->itemsize, dout.p, out_itemsize, n, dl.p, lut_len, fillw);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(host_dst, dout.p, n * out_itemsize, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dl.release(); dout.release();
+    if (e != hipSuccess) return fail(TA_EHIP, "map: %s", hipGetErrorString(e));
+    return TA_OK;
+}
+
 TA_API int ta_volume_max_label(ta_ctx* c, uint32_t* max_label) {
     if (!c || !max_label) return fail(TA_EINVAL, "NULL argument");
     if (!c->vol) return fail(TA_EINVAL, "no volume set");

@@ -18,6 +18,9 @@ void launch_pairs_pack(hipStream_t s, const uint64_t* keys, const uint64_t* face
                        const uint32_t* flags, uint64_t* block, uint64_t cap);
 void launch_pairs_insert_blocks(hipStream_t s, const PairTable& pt, const uint64_t* blocks, int nblocks,
                                 uint64_t cap, uint32_t* flags);
+void launch_relabel(hipStream_t s, void* vol, int itemsize, uint64_t n, const uint32_t* lut, uint32_t lut_len);
+void launch_map(hipStream_t s, const void* vol, int itemsize, void* out, int out_itemsize, uint64_t n,
+                const void* lut, uint32_t lut_len, uint64_t fill);
 void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3], int64_t a_begin,
                   int64_t a_count, const int32_t* seeds_dev, const int32_t grid[3],
                   const int64_t* ell_dev);

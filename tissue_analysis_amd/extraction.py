@@ -149,6 +149,20 @@ def full_mask():
     return _capi.F_ALL
 
 
+def extract_resident(ctx, shape, features=_capi.F_ALL, max_label=None):
+    """Run the sweep on the volume already resident in `ctx` and fetch the result."""
+    if max_label is None:
+        max_label = ctx.max_label()
+    ctx.extract(features, max_label)
+    count, bbox, sum1, sum2 = ctx.labels()
+    if _capi.feature_mask(features) & _capi.F_ADJACENCY:
+        lo, hi, faces = ctx.adjacency()
+    else:
+        lo = hi = np.zeros(0, dtype=np.uint32)
+        faces = np.zeros((0, 3), dtype=np.uint64)
+    return Extraction(shape, max_label, count, bbox, sum1, sum2, lo, hi, faces, ctx.timing())
+
+
 def extract_volume(array, features=_capi.F_ALL, device=0, context=None, max_label=None,
                    impl=None, tile_planes=None):
     """Upload `array` (uint16/uint32, any dense layout) and run the fused sweep on the GPU."""
@@ -163,16 +177,39 @@ def extract_volume(array, features=_capi.F_ALL, device=0, context=None, max_labe
         if tile_planes is not None:
             ctx.set_option(_capi.OPT_TILE_PLANES, tile_planes)
         ctx.set_volume(a)
-        if max_label is None:
-            max_label = ctx.max_label()
-        ctx.extract(features, max_label)
-        count, bbox, sum1, sum2 = ctx.labels()
-        if _capi.feature_mask(features) & _capi.F_ADJACENCY:
-            lo, hi, faces = ctx.adjacency()
-        else:
-            lo = hi = np.zeros(0, dtype=np.uint32)
-            faces = np.zeros((0, 3), dtype=np.uint64)
-        return Extraction(a.shape, max_label, count, bbox, sum1, sum2, lo, hi, faces, ctx.timing())
+        return extract_resident(ctx, a.shape, features, max_label)
     finally:
         if own:
             ctx.close()
+
+
+def relabel_volume(array, lut, features=_capi.F_ALL, device=0):
+    """One upload: relabel `array` IN PLACE through `lut` on the GPU (v -> lut[v] for v < len(lut)),
+    copy it back, and sweep the relabelled volume.  `array` must be a writeable dense uint16/uint32
+    ndarray (any axis permutation).  Returns the Extraction of the new volume."""
+    a = array if array.ndim == 3 else array[:, :, None]
+    ctx = _capi.Context(device)
+    try:
+        ctx.set_volume(a)
+        ctx.relabel(lut)
+        ctx.get_volume(a)
+        return extract_resident(ctx, a.shape, features)
+    finally:
+        ctx.close()
+
+
+def map_volume(array, lut, fill, device=0):
+    """out[p] = lut[array[p]] (fill beyond the table) on the GPU; `lut` fixes the output dtype."""
+    a = np.asarray(array)
+    flat = a.ndim == 2
+    if flat:
+        a = a[:, :, None]
+    if a.dtype not in (np.uint16, np.uint32) or not _capi._dense_permuted(a):
+        a = np.ascontiguousarray(a, dtype=np.uint16 if a.dtype.itemsize <= 2 else np.uint32)
+    ctx = _capi.Context(device)
+    try:
+        ctx.set_volume(a)
+        out = ctx.map_labels(lut, fill, a)
+    finally:
+        ctx.close()
+    return out[:, :, 0] if flat else out

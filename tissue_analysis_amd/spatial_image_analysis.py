@@ -369,6 +369,82 @@ class AbstractSpatialImageAnalysis(object):
         return self._cell_layer2
 
 
+    # -- image mutation (SIA:1114-1176): one lookup-table sweep on the GPU instead of per-label crops.
+    # The reference leaves its caches (_labels, _bbox, _neighbors ...) stale after these calls; here the
+    # relabelled volume is swept again in the same upload, so every later answer describes the new image.
+    def _relabel_image(self, mapping):
+        from .extraction import relabel_volume
+        img = np.asarray(self.image)
+        work = img if img.ndim == 3 else img[:, :, None]
+        direct = work.dtype in (np.uint16, np.uint32) and _capi._dense_permuted(work) and work.flags.writeable
+        if not direct:
+            wide = work.size and int(work.max()) > 65535
+            work = np.ascontiguousarray(work, dtype=np.uint32 if wide else np.uint16)
+        top = np.iinfo(work.dtype).max
+        lut = np.arange(self._x.max_label + 1, dtype=np.uint32)
+        for old, new in mapping.items():
+            if not (0 <= int(new) <= top):
+                raise ValueError("value %r does not fit the image dtype %s" % (new, work.dtype))
+            if 0 <= int(old) <= self._x.max_label:
+                lut[int(old)] = int(new)
+        x = relabel_volume(work, lut, device=self._device)
+        if not direct:
+            np.copyto(self.image if img.ndim == 3 else self.image[:, :, None], work.astype(img.dtype), casting="unsafe")
+        self._x = x
+        self._labels = None
+        self._bbox = None
+        self._neighbors = None
+        self._cell_layer1 = None
+        self._center_of_mass = {}
+
+    def fuse_labels_in_image(self, labels, verbose=True):  # SIA:1114-1136
+        """Modify the image so the given labels are fused (to the min value)."""
+        assert isinstance(labels, list) and len(labels) >= 2
+        assert self.background() not in labels
+        min_lab = min(labels)
+        labels.remove(min_lab)                      # the caller's list loses its minimum, as in the reference
+        if verbose:
+            print("Fusing the following {} labels: {} to value '{}'.".format(len(labels), labels, min_lab))
+        self._relabel_image(dict((l, min_lab) for l in labels))
+        return None
+
+    def remove_labels_from_image(self, labels, erase_value=0, verbose=True):  # SIA:1138-1165
+        if isinstance(labels, _INT):
+            labels = [labels]
+        try:
+            labels.remove(self.background())
+        except ValueError:
+            pass
+        if verbose:
+            print("Removing", len(labels), "cell-labels.")
+        self._relabel_image(dict((l, erase_value) for l in labels))
+        self._ignoredlabels.update([erase_value])
+        for label in labels:
+            self._ignoredlabels.discard(label)
+
+    def remove_stack_margin_labels_from_image(self, erase_value=0, voxel_distance_from_margin=5,
+                                              verbose=True):  # SIA:1168-1176
+        self.remove_labels_from_image(self.labels_at_stack_margins(voxel_distance_from_margin), erase_value, verbose)
+
+    def property_image(self, property_dict, dtype=np.uint16):
+        """Image of a per-label property (PropertySpatialImage.create_property_image, PSI:207-221):
+        labels without a value, and the background, map to the background id; values are cast with
+        ``astype(dtype)`` per label, which is what the reference does per voxel."""
+        from .extraction import map_volume
+        bg = self.background()
+        if bg is None:
+            raise ValueError("property_image needs the background label")
+        dtype = np.dtype(dtype)
+        lut = np.full(self._x.max_label + 1, bg, dtype=np.float64)
+        for l, v in property_dict.items():
+            if 0 <= int(l) <= self._x.max_label and int(l) != bg:
+                lut[int(l)] = v
+        with np.errstate(invalid="ignore"):
+            lut = lut.astype(dtype)
+        out = map_volume(np.asarray(self.image), lut, np.array(bg).astype(dtype), device=self._device)
+        return SpatialImage(out, voxelsize=getattr(self.image, "voxelsize", None))
+
+
 class SpatialImageAnalysis3D(AbstractSpatialImageAnalysis):
     """SIA:1179-1448 (volume, inertia, margins) on top of the same sweep."""
 
