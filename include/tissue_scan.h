@@ -57,9 +57,11 @@ extern "C" {
 #define TA_F_ALL       31u
 
 /* ta_ctx_set_option keys */
-#define TA_OPT_IMPL        1  /* 0 = fused LDS sweep (default), 1 = per-voxel atomics (slow, for cross-checks),
-                                 2 = split: emit kernel -> record regions in HBM -> reduce kernel (falls back
-                                 to 0 by itself on volumes with more events than a region holds)              */
+#define TA_OPT_IMPL        1  /* 0 = default: the row-run sweep when no adjacency is requested, the fused
+                                 sweep when it is; 1 = per-voxel atomics (slow, for cross-checks); 2 = split
+                                 emit / reduce kernels (diagnostic; falls back to the fused sweep by itself
+                                 on volumes with more events than a region holds); 3 = row-run sweep (runs
+                                 along the contiguous axis) always; 4 = fused sweep (runs along axis 0) always */
 #define TA_OPT_TILE_PLANES 2  /* planes of memory axis 0 walked by one workgroup (tuning)          */
 #define TA_OPT_PAIR_SLOTS  3  /* log2 of the device adjacency hash capacity (0 = automatic)       */
 

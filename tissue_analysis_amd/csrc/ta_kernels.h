@@ -30,6 +30,7 @@ void launch_sweep(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feat
 // split path: sizes of the record regions for a volume (wave tiles, face / run records per tile)
 void split_region_shape(const SweepArgs& a, int itemsize, uint64_t* wave_tiles, uint32_t* fcap, uint32_t* rcap);
 void launch_split(hipStream_t s, const SplitArgs& a, int itemsize, uint32_t feature_mask);
+void launch_rowrun(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);   // kernels_rowrun.hip
 int sweep_default_tile_planes();
 int sweep_max_tile_planes();
 

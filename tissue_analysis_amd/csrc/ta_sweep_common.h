@@ -1,0 +1,247 @@
+// ta_sweep_common.h -- pieces shared by the sweep kernels (kernels_sweep.hip, kernels_rowrun.hip):
+// tuning constants, register-level helpers (DPP shift, mask prefix, strip loads), the workgroup LDS
+// hash tables (label -> packed tile-local moments + bbox, pair -> per-axis face counts) and their flush.
+#pragma once
+#include "ta_kernels.h"
+
+namespace ta {
+
+#ifndef TA_ABLATE
+#define TA_ABLATE 0     // experiments only: 1 = records are produced but not consumed
+#endif
+#ifndef TA_WAVES
+#define TA_WAVES 4
+#endif
+#ifndef TA_RB32
+#define TA_RB32 4
+#endif
+#ifndef TA_QCAP
+#define TA_QCAP 256
+#endif
+#ifndef TA_PSLOTS
+#define TA_PSLOTS 512
+#endif
+#ifndef TA_LSLOTS
+#define TA_LSLOTS 128
+#endif
+#ifndef TA_PREFETCH
+#define TA_PREFETCH 1
+#endif
+#ifndef TA_MINWAVES
+#define TA_MINWAVES 4             // waves per SIMD the register allocator must leave room for
+#endif
+constexpr int WAVES = TA_WAVES;   // waves per workgroup, stacked along axis 1
+constexpr int QCAP = TA_QCAP;     // per-wave ring capacity (records); one block adds <= 64
+constexpr int LSLOTS = TA_LSLOTS; // label table slots per workgroup
+constexpr int PSLOTS = TA_PSLOTS; // pair table slots per workgroup
+constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
+constexpr int LSLOTS_LOG2 = ilog2_c(LSLOTS), PSLOTS_LOG2 = ilog2_c(PSLOTS);
+static_assert((1 << LSLOTS_LOG2) == LSLOTS && (1 << PSLOTS_LOG2) == PSLOTS, "table sizes must be powers of two");
+constexpr int LPROBE = 16;        // max probes before spilling to global atomics
+constexpr int PPROBE = 32;
+constexpr int MAX_TILE_PLANES = 64;
+constexpr uint32_t LABEL_LIMIT = 1u << 28;    // max_label < 2^28: the two top bits of a record word are free
+
+__device__ __forceinline__ uint32_t lane_shr1(uint32_t src, uint32_t lane0_value) {
+    // lane i <- src of lane i-1 ; lane 0 keeps lane0_value   (DPP wave_shr:1)
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)src, 0x138, 0xf, 0xf, false);
+}
+
+__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// ---- strip loads ---------------------------------------------------------------------------
+// `row_c0` points at the wave's first voxel of the row (wave-uniform, lives in SGPRs); lanes add a
+// 32-bit byte offset, so the 16-byte loads use the saddr + voffset form and no 64-bit VGPR address.
+template <typename T, int VPL>
+__device__ __forceinline__ void load_strip(const bool EDGE, const T* row_c0, bool row_ok, uint32_t lane_off,
+                                           int64_t c, int64_t n2, uint32_t (&dst)[VPL]) {
+    if (!EDGE) {
+        const uint4 x = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(row_c0) + lane_off);
+        if (sizeof(T) == 4) {
+            dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
+        } else {
+            dst[0] = x.x & 0xffffu; dst[1] = x.x >> 16; dst[2] = x.y & 0xffffu; dst[3] = x.y >> 16;
+            dst[4 % VPL] = x.z & 0xffffu; dst[5 % VPL] = x.z >> 16;
+            dst[6 % VPL] = x.w & 0xffffu; dst[7 % VPL] = x.w >> 16;
+        }
+    } else {
+        const T* lane_p = reinterpret_cast<const T*>(reinterpret_cast<const char*>(row_c0) + lane_off);
+#pragma unroll
+        for (int j = 0; j < VPL; ++j)
+            dst[j] = (row_ok && c + j < n2) ? (uint32_t)lane_p[j] : INVALID_LABEL;
+    }
+}
+
+// one voxel at a wave-uniform address through the scalar cache (SMEM): no VGPR, no vector-memory slot
+template <typename T>
+__device__ __forceinline__ uint32_t load_uniform_voxel(const T* p) {
+    typedef const __attribute__((address_space(4))) uint32_t* cptr;
+    const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+    const uint32_t word = *reinterpret_cast<cptr>(a & ~(uintptr_t)3);
+    if (sizeof(T) == 4) return word;
+    return (a & 2) ? (word >> 16) : (word & 0xffffu);
+}
+
+// local sums of one label contribution (tile-local coordinates)
+struct LocalSums { uint64_t n, sa, sb, sc, saa, sab, sac, sbb, sbc, scc; };
+// one run's contribution: every term fits 32 bits (n <= 64, a < 64, b < 16, c < 512)
+struct RunSums { uint32_t n, sa, sb, sc, saa, sab, sac, sbb, sbc, scc; };
+
+// shift tile-local sums to global coordinates (origin A0,B0,C0): exact u64
+__device__ __forceinline__ void local_to_global(const LocalSums& L, uint64_t A0, uint64_t B0, uint64_t C0,
+                                                uint64_t (&g)[NSUM]) {
+    g[0] = L.n;
+    g[1] = L.sa + L.n * A0; g[2] = L.sb + L.n * B0; g[3] = L.sc + L.n * C0;
+    g[4] = L.saa + 2 * A0 * L.sa + L.n * A0 * A0;
+    g[5] = L.sab + A0 * L.sb + B0 * L.sa + L.n * A0 * B0;
+    g[6] = L.sac + A0 * L.sc + C0 * L.sa + L.n * A0 * C0;
+    g[7] = L.sbb + 2 * B0 * L.sb + L.n * B0 * B0;
+    g[8] = L.sbc + B0 * L.sc + C0 * L.sb + L.n * B0 * C0;
+    g[9] = L.scc + 2 * C0 * L.sc + L.n * C0 * C0;
+}
+
+// ---- rare spill paths, kept out of line so they do not bloat the hot loops ------------------
+static __device__ __noinline__ void label_spill_global(uint64_t* sums, int32_t* boxes, uint32_t* flags,
+                                                uint32_t max_label, uint32_t label, const LocalSums* L,
+                                                uint64_t A0, uint64_t B0, uint64_t C0, const uint32_t* box) {
+    atomicAdd(&flags[FLAG_LDS_LABEL_SPILL], 1u);
+    if (label > max_label) { atomicOr(&flags[FLAG_RANGE], 1u); return; }
+    uint64_t g[NSUM];
+    local_to_global(*L, A0, B0, C0, g);
+    unsigned long long* row = (unsigned long long*)&sums[(uint64_t)label * NSUM];
+    for (int k = 0; k < NSUM; ++k) if (g[k]) atomicAdd(row + k, (unsigned long long)g[k]);
+    int32_t* gb = &boxes[(uint64_t)label * NBOX];
+    atomicMin(gb + 0, (int32_t)(A0 + box[0])); atomicMin(gb + 3, -(int32_t)(A0 + box[3]));
+    atomicMin(gb + 1, (int32_t)(B0 + box[1])); atomicMin(gb + 4, -(int32_t)(B0 + box[4]));
+    atomicMin(gb + 2, (int32_t)(C0 + box[2])); atomicMin(gb + 5, -(int32_t)(C0 + box[5]));
+}
+
+static __device__ __noinline__ void pair_spill_global(PairTable pt, uint32_t* flags, uint32_t lo, uint32_t hi,
+                                               uint32_t axis, uint32_t count) {
+    atomicAdd(&flags[FLAG_LDS_PAIR_SPILL], 1u);
+    pair_add_global(pt, lo, hi, axis == 0 ? count : 0, axis == 1 ? count : 0, axis == 2 ? count : 0, flags);
+}
+
+// ---- workgroup-shared LDS tables -----------------------------------------------------------
+struct TileFrame { uint64_t A0, B0, C0; };     // origin of the tile-local frame
+
+template <bool MOM2, typename LDS, typename SUMS>
+__device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, const TileFrame& F, uint32_t label,
+                                              const SUMS& L, uint32_t mna, uint32_t mxa, uint32_t mnb,
+                                              uint32_t mxb, uint32_t mnc, uint32_t mxc) {
+    constexpr int NW = MOM2 ? 6 : 2;
+    // Fibonacci hashing modulo 2^24 on the full-rate 24-bit multiplier: top bits of the low 24 product bits
+    uint32_t h = (__umul24(label, 0x9E3779u) >> (24 - LSLOTS_LOG2)) & (LSLOTS - 1);
+    int slot = -1;
+#pragma nounroll
+    for (int probe = 0; probe < LPROBE; ++probe) {
+        uint32_t k = S.lkeys[h];
+        if (k == INVALID_LABEL) {
+            k = atomicCAS(&S.lkeys[h], INVALID_LABEL, label);
+            if (k == INVALID_LABEL) k = label;
+        }
+        if (k == label) { slot = (int)h; break; }
+        h = (h + 1) & (LSLOTS - 1);
+    }
+    if (slot >= 0) {
+        unsigned long long* row = (unsigned long long*)&S.lsum[slot * NW];
+        atomicAdd(row + 0, (unsigned long long)((uint64_t)L.n | ((uint64_t)L.sb << 32)));
+        atomicAdd(row + 1, (unsigned long long)((uint64_t)L.sa | ((uint64_t)L.sc << 32)));
+        if (MOM2) {
+            atomicAdd(row + 2, (unsigned long long)((uint64_t)L.saa | ((uint64_t)L.sab << 32)));
+            atomicAdd(row + 3, (unsigned long long)((uint64_t)L.sbb | ((uint64_t)L.sbc << 32)));
+            atomicAdd(row + (MOM2 ? 4 : 0), (unsigned long long)L.sac);
+            atomicAdd(row + (MOM2 ? 5 : 0), (unsigned long long)L.scc);
+        }
+        // bounding box: read first, touch the atomics only when this contribution extends it
+        uint32_t* box = &S.lbox[slot * 8];
+        const uint4 cur = *reinterpret_cast<const uint4*>(box);          // min a,b,c | max a
+        const uint2 cur2 = *reinterpret_cast<const uint2*>(box + 4);     // max b,c
+        if (mna < cur.x) atomicMin(box + 0, mna);
+        if (mnb < cur.y) atomicMin(box + 1, mnb);
+        if (mnc < cur.z) atomicMin(box + 2, mnc);
+        if (mxa > cur.w) atomicMax(box + 3, mxa);
+        if (mxb > cur2.x) atomicMax(box + 4, mxb);
+        if (mxc > cur2.y) atomicMax(box + 5, mxc);
+    } else {                                       // table full: straight to the global rows
+        // copies made HERE so that only this cold branch (not the hot path) has address-taken locals
+        LocalSums Lc;
+        Lc.n = L.n; Lc.sa = L.sa; Lc.sb = L.sb; Lc.sc = L.sc; Lc.saa = L.saa; Lc.sab = L.sab;
+        Lc.sac = L.sac; Lc.sbb = L.sbb; Lc.sbc = L.sbc; Lc.scc = L.scc;
+        uint32_t bx[6];
+        bx[0] = mna; bx[1] = mnb; bx[2] = mnc; bx[3] = mxa; bx[4] = mxb; bx[5] = mxc;
+        label_spill_global(A.sums, A.boxes, A.flags, A.max_label, label, &Lc, F.A0, F.B0, F.C0, bx);
+    }
+}
+
+template <typename LDS>
+__device__ __forceinline__ void lds_pair_add(const SweepArgs& A, LDS& S, uint32_t a, uint32_t b,
+                                             uint32_t axis, uint32_t count) {
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    const uint64_t key = ((uint64_t)lo << 32) | hi;
+    uint32_t h = __umul24(lo, 0x9E3779u) + __umul24(hi, 0x85EBCBu);     // two full-rate 24-bit multiplies, modulo 2^24
+    h = (h >> (24 - PSLOTS_LOG2)) & (PSLOTS - 1);
+    int slot = -1;
+#pragma nounroll
+    for (int probe = 0; probe < PPROBE; ++probe) {
+        uint64_t k = S.pkeys[h];
+        if (k == EMPTY_KEY) {
+            k = atomicCAS((unsigned long long*)&S.pkeys[h], (unsigned long long)EMPTY_KEY,
+                          (unsigned long long)key);
+            if (k == EMPTY_KEY) k = key;
+        }
+        if (k == key) { slot = (int)h; break; }
+        h = (h + 1) & (PSLOTS - 1);
+    }
+    if (slot >= 0) atomicAdd(&S.pcnt[slot * 3 + axis], count);
+    else pair_spill_global(A.pairs, A.flags, lo, hi, axis, count);
+}
+
+// sum_{x=x0}^{x0+n-1} x  and  x^2  (exact, u64)
+__device__ __forceinline__ uint64_t range_sum1(uint64_t x0, uint64_t n) { return n * x0 + n * (n - 1) / 2; }
+__device__ __forceinline__ uint64_t range_sum2(uint64_t x0, uint64_t n) {
+    return n * x0 * x0 + x0 * n * (n - 1) + (n - 1) * n * (2 * n - 1) / 6;
+}
+
+// ---- flush the workgroup tables with global atomics (local -> global coordinates here) -------
+template <int NW, bool ADJ, bool MOM2, typename LDS>
+__device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const int tid, const uint64_t A0,
+                                             const uint64_t B0, const uint64_t C0) {
+    for (int i = tid; i < LSLOTS; i += WAVES * 64) {
+        const uint32_t label = S.lkeys[i];
+        if (label == INVALID_LABEL) continue;
+        if (label > A.max_label) { atomicOr(&A.flags[FLAG_RANGE], 1u); continue; }
+        const uint64_t w0 = S.lsum[i * NW + 0], w1 = S.lsum[i * NW + 1];
+        LocalSums L;
+        L.n = w0 & 0xffffffffull; L.sb = w0 >> 32; L.sa = w1 & 0xffffffffull; L.sc = w1 >> 32;
+        if (MOM2) {
+            const uint64_t w2 = S.lsum[i * NW + (MOM2 ? 2 : 0)], w3 = S.lsum[i * NW + (MOM2 ? 3 : 0)];
+            L.saa = w2 & 0xffffffffull; L.sab = w2 >> 32;
+            L.sbb = w3 & 0xffffffffull; L.sbc = w3 >> 32;
+            L.sac = S.lsum[i * NW + (MOM2 ? 4 : 0)]; L.scc = S.lsum[i * NW + (MOM2 ? 5 : 0)];
+        } else {
+            L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
+        }
+        uint64_t g[NSUM];
+        local_to_global(L, A0, B0, C0, g);
+        unsigned long long* row = (unsigned long long*)&A.sums[(uint64_t)label * NSUM];
+#pragma unroll
+        for (int k = 0; k < (MOM2 ? NSUM : 4); ++k) atomicAdd(row + k, (unsigned long long)g[k]);
+        int32_t* box = &A.boxes[(uint64_t)label * NBOX];
+        atomicMin(box + 0, (int32_t)(A0 + S.lbox[i * 8 + 0])); atomicMin(box + 3, -(int32_t)(A0 + S.lbox[i * 8 + 3]));
+        atomicMin(box + 1, (int32_t)(B0 + S.lbox[i * 8 + 1])); atomicMin(box + 4, -(int32_t)(B0 + S.lbox[i * 8 + 4]));
+        atomicMin(box + 2, (int32_t)(C0 + S.lbox[i * 8 + 2])); atomicMin(box + 5, -(int32_t)(C0 + S.lbox[i * 8 + 5]));
+    }
+    if (ADJ) {
+        for (int i = tid; i < PSLOTS; i += WAVES * 64) {
+            const uint64_t key = S.pkeys[i];
+            if (key == EMPTY_KEY) continue;
+            pair_add_global(A.pairs, (uint32_t)(key >> 32), (uint32_t)key, S.pcnt[i * 3 + 0],
+                            S.pcnt[i * 3 + 1], S.pcnt[i * 3 + 2], A.flags);
+        }
+    }
+}
+
+}  // namespace ta
