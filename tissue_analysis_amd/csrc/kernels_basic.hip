@@ -8,7 +8,7 @@ namespace ta {
 // ------------------------------------------------------------------------------------------
 // accumulator init: sums = 0, boxes = INT32_MAX, flags = 0, cursor = 0 (one launch, 16 B stores)
 __global__ void __launch_bounds__(256) init_kernel(uint64_t* sums, int32_t* boxes, uint64_t nlabels,
-                                                   uint32_t* flags, uint32_t* cursor) {
+                                                   uint32_t* flags, uint32_t* cursor, uint64_t* hot_rows) {
     const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t nthreads = (uint64_t)gridDim.x * blockDim.x;
     const uint64_t nsum2 = nlabels * NSUM / 2;              // NSUM is even: ulong2 stores
@@ -18,17 +18,20 @@ __global__ void __launch_bounds__(256) init_kernel(uint64_t* sums, int32_t* boxe
     int2* b2 = reinterpret_cast<int2*>(boxes);
     for (uint64_t i = tid; i < nbox2; i += nthreads) b2[i] = make_int2(INT32_MAX, INT32_MAX);
     if (tid < NFLAGS) flags[tid] = 0u;
-    if (tid == 0) *cursor = 0u;
+    if (tid == 0) {
+        *cursor = 0u;
+        *reinterpret_cast<uint64_t**>(flags + HOT_PTR_WORD) = hot_rows;      // parked for the sweep kernels
+    }
 }
 
 void launch_init_accumulators(hipStream_t s, uint64_t* sums, int32_t* boxes, uint64_t nlabels,
-                              uint32_t* flags, uint32_t* pair_cursor) {
+                              uint32_t* flags, uint32_t* pair_cursor, uint64_t* hot_rows) {
     uint64_t work = nlabels * NSUM / 2;
     int blocks = (int)((work + 255) / 256);
     if (blocks < 1) blocks = 1;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(init_kernel, dim3(blocks), dim3(256), 0, s, sums, boxes, nlabels, flags,
-                       pair_cursor);
+                       pair_cursor, hot_rows);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -272,6 +275,46 @@ void launch_pairs_clear(hipStream_t s, const PairTable& pt) {
     uint64_t blocks = (cap + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pairs_clear_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pt);
+}
+
+// ------------------------------------------------------------------------------------------
+// Fold the per-workgroup private rows of the hot label (ta_sweep_common.h: flush_tables) into its
+// global row.  Row = 128 bytes: sums u64[NSUM] | boxes i32[NBOX] | padding.
+__global__ void __launch_bounds__(256) hot_reduce_kernel(const uint64_t* __restrict__ rows, uint32_t nrows,
+                                                         const void* vol, int itemsize, int64_t corner,
+                                                         uint64_t* sums, int32_t* boxes, uint32_t max_label) {
+    __shared__ uint64_t part[256];
+    const uint32_t hot = itemsize == 2 ? (uint32_t)((const uint16_t*)vol)[corner] : ((const uint32_t*)vol)[corner];
+    if (hot > max_label) return;                           // the sweep has raised FLAG_RANGE already
+    const int col = threadIdx.x & (HOTW - 1), lanegrp = threadIdx.x / HOTW;          // 16 row-lanes per block
+    const bool is_sum = col < NSUM;
+    int64_t acc = is_sum ? 0 : (int64_t)INT32_MAX;
+    for (uint32_t r = blockIdx.x * (256 / HOTW) + lanegrp; r < nrows; r += gridDim.x * (256 / HOTW)) {
+        if (is_sum) acc += (int64_t)rows[(uint64_t)r * HOTW + col];
+        else {
+            const int32_t v = reinterpret_cast<const int32_t*>(rows + (uint64_t)r * HOTW + NSUM)[col - NSUM];
+            acc = v < acc ? v : acc;
+        }
+    }
+    part[threadIdx.x] = (uint64_t)acc;
+    __syncthreads();
+    if (lanegrp == 0) {
+        for (int g = 1; g < 256 / HOTW; ++g) {
+            const int64_t v = (int64_t)part[g * HOTW + col];
+            if (is_sum) acc += v;
+            else acc = v < acc ? v : acc;
+        }
+        if (is_sum) { if (acc) atomicAdd((unsigned long long*)&sums[(uint64_t)hot * NSUM + col], (unsigned long long)acc); }
+        else atomicMin(&boxes[(uint64_t)hot * NBOX + (col - NSUM)], (int32_t)acc);
+    }
+}
+
+void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows) {
+    if (!hot_rows || nrows == 0) return;
+    uint32_t blocks = (nrows + 15) / 16;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(hot_reduce_kernel, dim3(blocks), dim3(256), 0, s, hot_rows, nrows, a.vol, itemsize,
+                       (int64_t)a.first_owned * a.n1 * a.n2, a.sums, a.boxes, a.max_label);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -350,6 +350,7 @@ __global__ void __launch_bounds__(WAVES * 64, TA_MINWAVES) rowrun_kernel(SweepAr
             S.pcnt[i * 3 + 0] = 0u; S.pcnt[i * 3 + 1] = 0u; S.pcnt[i * 3 + 2] = 0u;
         }
     }
+    if (!ADJ) hot_row_init(A, tid);          // the hot-label rows are used by the variants without adjacency only
     __syncthreads();
 
     const int64_t tiles_c = (A.n2 + TC - 1) / TC, tiles_b = (A.n1 + TB - 1) / TB;
@@ -367,7 +368,8 @@ __global__ void __launch_bounds__(WAVES * 64, TA_MINWAVES) rowrun_kernel(SweepAr
         wave_rowrun<T, VPL, RB, ADJ, MOM2>(A, S, !interior, lane, w, c_tile0, b_tile0, p_lo, p_hi);
     }
     __syncthreads();
-    flush_tables<NW, ADJ, MOM2>(A, S, tid, (uint64_t)(A.a_origin + (p_lo - A.first_owned)), (uint64_t)b_tile0, (uint64_t)c_tile0);
+    flush_tables<NW, ADJ, MOM2, !ADJ>(A, S, tid, (uint64_t)(A.a_origin + (p_lo - A.first_owned)), (uint64_t)b_tile0,
+                                      (uint64_t)c_tile0, ADJ ? 0u : hot_label_of<T>(A));
 }
 
 template <typename T, int VPL, int RB>

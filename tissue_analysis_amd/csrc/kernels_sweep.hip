@@ -443,7 +443,7 @@ __global__ void __launch_bounds__(WAVES * 64, TA_MINWAVES) sweep_kernel(SweepArg
     }
     __syncthreads();
 
-    flush_tables<NW, ADJ, MOM2>(A, S, tid, (uint64_t)(A.a_origin + (p_lo - A.first_owned)), (uint64_t)b_tile0, (uint64_t)c_tile0);
+    flush_tables<NW, ADJ, MOM2, false>(A, S, tid, (uint64_t)(A.a_origin + (p_lo - A.first_owned)), (uint64_t)b_tile0, (uint64_t)c_tile0, 0u);
 }
 
 // =================================================================================================
@@ -736,7 +736,7 @@ __global__ void __launch_bounds__(WAVES * 64) reduce_kernel(SplitArgs P) {
                                             (uint32_t)(nc - 1));
     }
     __syncthreads();
-    flush_tables<NW, ADJ, MOM2>(A, S, tid, F.A0, F.B0, F.C0);
+    flush_tables<NW, ADJ, MOM2, false>(A, S, tid, F.A0, F.B0, F.C0, 0u);
 }
 
 template <int VPL, int RB>
@@ -774,6 +774,12 @@ static void launch_split_t(hipStream_t s, const SplitArgs& a, uint32_t fm) {
 void launch_split(hipStream_t s, const SplitArgs& a, int itemsize, uint32_t feature_mask) {
     if (itemsize == 2) launch_split_t<uint16_t, 8, 2>(s, a, feature_mask);
     else               launch_split_t<uint32_t, 4, TA_RB32>(s, a, feature_mask);
+}
+
+uint64_t sweep_grid_size(const SweepArgs& a, int itemsize) {
+    uint64_t wave_tiles; uint32_t f, r;
+    split_region_shape(a, itemsize, &wave_tiles, &f, &r);
+    return wave_tiles / WAVES;
 }
 
 int sweep_default_tile_planes() { return 32; }   // 64 planes start to overflow the 128-slot label table

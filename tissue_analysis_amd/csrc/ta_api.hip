@@ -78,6 +78,7 @@ struct ta_ctx {
     // adjacency
     DevBuf pkeys, pfaces, out_keys, out_faces, small;   // small: flags[NFLAGS] | cursor | maxlabel
     DevBuf split_f, split_r, split_hdr;                 // record regions of the split path (TA_OPT_IMPL = 2)
+    DevBuf hot_rows;                                    // [workgroups][16] private rows of the hot label
     bool split_failed = false;                          // a region overflowed on this volume: use the fused sweep
     int pair_log2 = 0;                                  // current table log2 capacity
     int opt_pair_log2 = 0;
@@ -97,7 +98,7 @@ struct ta_ctx {
 
 namespace {
 
-constexpr int SMALL_WORDS = ta::NFLAGS + 2;   // flags, cursor, max label
+constexpr int SMALL_WORDS = ta::NFLAGS + 4;   // flags, cursor, max label, parked hot-row pointer (2 words)
 
 uint32_t* flags_dev(ta_ctx* c) { return (uint32_t*)c->small.p; }
 uint32_t* cursor_dev(ta_ctx* c) { return (uint32_t*)c->small.p + ta::NFLAGS; }
@@ -145,6 +146,10 @@ int run_extract(ta_ctx* c) {
     a.a_origin = c->a_origin;
     a.first_owned = c->first_owned;
     a.tile_planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes();
+    if (c->tile_planes <= 0) {
+        // automatic: small volumes get shorter tiles until the launch has >= 2048 workgroups (8 per CU)
+        while (a.tile_planes > 8 && ta::sweep_grid_size(a, c->itemsize) < 2048) a.tile_planes /= 2;
+    }
     if (a.tile_planes > ta::sweep_max_tile_planes()) a.tile_planes = ta::sweep_max_tile_planes();   // packed LDS moment words
     a.vec_ok = (((uintptr_t)c->vol & 15) == 0) && ((a.n2 * c->itemsize) % 16 == 0);
     a.max_label = c->max_label;
@@ -152,6 +157,15 @@ int run_extract(ta_ctx* c) {
     a.boxes = c->boxes;
     a.pairs = pair_table(c);
     a.flags = flags_dev(c);
+    uint64_t* hot_rows = nullptr;
+    uint64_t nwg = 0;
+    const bool rowrun = c->impl == 3 || (c->impl == 0 && !(c->feature_mask & TA_F_ADJACENCY));
+    if (rowrun && !(c->feature_mask & TA_F_ADJACENCY)) {     // the kernels that use the private hot-label rows
+        nwg = ta::sweep_grid_size(a, c->itemsize);
+        int rc0 = c->hot_rows.reserve(nwg * ta::HOTW * 8);
+        if (rc0 != TA_OK) return rc0;
+        hot_rows = (uint64_t*)c->hot_rows.p;
+    }
 
     const bool adj = c->feature_mask & TA_F_ADJACENCY;
     TA_HIP(hipEventRecord(c->ev[0], c->stream));
@@ -159,7 +173,7 @@ int run_extract(ta_ctx* c) {
         ta::launch_pairs_clear(c->stream, a.pairs);
         c->table_clean = true;
     }
-    ta::launch_init_accumulators(c->stream, c->sums, c->boxes, nlabels, flags_dev(c), cursor_dev(c));
+    ta::launch_init_accumulators(c->stream, c->sums, c->boxes, nlabels, flags_dev(c), cursor_dev(c), hot_rows);
     TA_HIP(hipEventRecord(c->ev[1], c->stream));
     if (c->impl == 1) {
         ta::launch_naive(c->stream, a, c->itemsize, c->feature_mask);
@@ -181,6 +195,7 @@ int run_extract(ta_ctx* c) {
     } else {
         ta::launch_sweep(c->stream, a, c->itemsize, c->feature_mask);
     }
+    if (hot_rows) ta::launch_hot_reduce(c->stream, a, c->itemsize, hot_rows, (uint32_t)nwg);
     TA_HIP(hipEventRecord(c->ev[2], c->stream));
     if (adj)
         ta::launch_pairs_collect(c->stream, a.pairs, (uint64_t*)c->out_keys.p, (uint64_t*)c->out_faces.p,
@@ -283,7 +298,7 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     c->owned_vol.release(); c->own_sums.release(); c->own_boxes.release();
     c->pkeys.release(); c->pfaces.release(); c->out_keys.release(); c->out_faces.release();
     c->small.release();
-    c->split_f.release(); c->split_r.release(); c->split_hdr.release();
+    c->split_f.release(); c->split_r.release(); c->split_hdr.release(); c->hot_rows.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);

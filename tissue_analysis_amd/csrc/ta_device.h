@@ -40,8 +40,14 @@ struct SweepArgs {
     uint64_t* sums;          // [max_label+1][NSUM]
     int32_t* boxes;          // [max_label+1][NBOX]
     PairTable pairs;
-    uint32_t* flags;         // [NFLAGS]
+    uint32_t* flags;         // [NFLAGS] flag words, then cursor, max label, and the hot-row pointer (HOT_PTR_WORD)
 };
+// Private rows for the "hot" label (the one at the slab's first voxel -- the background), see flush_tables /
+// hot_reduce_kernel.  The pointer to them ([workgroups][HOTW] u64, or NULL) is NOT a kernel argument: the
+// sweep kernels sit on the edge of their register budget, so it is parked behind the flag words by
+// init_kernel and fetched with a scalar load where it is needed.
+constexpr int HOTW = 16;             // u64 words of a hot row: sums u64[NSUM] | boxes i32[NBOX] | padding
+constexpr int HOT_PTR_WORD = NFLAGS + 2;   // uint32 index into the flags buffer, 8-byte aligned
 
 // split path (emit kernel -> record regions in HBM -> reduce kernel); one region per wave tile
 struct SplitArgs {

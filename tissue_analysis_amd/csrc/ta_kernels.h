@@ -6,7 +6,7 @@ namespace ta {
 
 // kernels_basic.hip
 void launch_init_accumulators(hipStream_t s, uint64_t* sums, int32_t* boxes, uint64_t nlabels,
-                              uint32_t* flags, uint32_t* pair_cursor);
+                              uint32_t* flags, uint32_t* pair_cursor, uint64_t* hot_rows);
 void launch_naive(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);
 void launch_max_label(hipStream_t s, const void* vol, int itemsize, uint64_t nvox, uint32_t* out_dev);
 void launch_pairs_collect(hipStream_t s, const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces,
@@ -18,6 +18,7 @@ void launch_pairs_pack(hipStream_t s, const uint64_t* keys, const uint64_t* face
                        const uint32_t* flags, uint64_t* block, uint64_t cap);
 void launch_pairs_insert_blocks(hipStream_t s, const PairTable& pt, const uint64_t* blocks, int nblocks,
                                 uint64_t cap, uint32_t* flags);
+void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows);
 void launch_relabel(hipStream_t s, void* vol, int itemsize, uint64_t n, const uint32_t* lut, uint32_t lut_len);
 void launch_map(hipStream_t s, const void* vol, int itemsize, void* out, int out_itemsize, uint64_t n,
                 const void* lut, uint32_t lut_len, uint64_t fill);
@@ -31,6 +32,7 @@ void launch_sweep(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feat
 void split_region_shape(const SweepArgs& a, int itemsize, uint64_t* wave_tiles, uint32_t* fcap, uint32_t* rcap);
 void launch_split(hipStream_t s, const SplitArgs& a, int itemsize, uint32_t feature_mask);
 void launch_rowrun(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);   // kernels_rowrun.hip
+uint64_t sweep_grid_size(const SweepArgs& a, int itemsize);   // workgroups of any of the sweep kernels
 int sweep_default_tile_planes();
 int sweep_max_tile_planes();
 

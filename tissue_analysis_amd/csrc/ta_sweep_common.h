@@ -206,9 +206,34 @@ __device__ __forceinline__ uint64_t range_sum2(uint64_t x0, uint64_t n) {
 }
 
 // ---- flush the workgroup tables with global atomics (local -> global coordinates here) -------
-template <int NW, bool ADJ, bool MOM2, typename LDS>
+// One label -- the background -- is in almost every tile of a tissue-in-a-box volume: thousands of
+// workgroups flushing it means tens of thousands of atomics on ONE row of the global accumulators, which
+// serialise in a single L2 channel (it is what made small tiles slow: C2 at 8-plane tiles 0.30 -> 0.12 ms).
+// The label of the slab's first voxel is taken as that hot label; every workgroup owns a private row for
+// it (plain stores, identity written in the prologue) and hot_reduce_kernel folds the rows afterwards.
+template <typename T>
+__device__ __forceinline__ uint32_t hot_label_of(const SweepArgs& A) {
+    return load_uniform_voxel<T>(reinterpret_cast<const T*>(A.vol) + (int64_t)A.first_owned * A.n1 * A.n2);
+}
+// row layout (HOTW u64 words = 128 bytes): sums u64[NSUM] | boxes i32[NBOX] | padding
+__device__ __forceinline__ uint64_t* hot_rows_of(const SweepArgs& A) {
+    typedef uint64_t* const __attribute__((address_space(4)))* cpp;          // scalar (SMEM) load of the parked pointer
+    return *reinterpret_cast<cpp>(reinterpret_cast<uintptr_t>(A.flags + HOT_PTR_WORD));
+}
+__device__ __forceinline__ void hot_row_init(const SweepArgs& A, const int tid) {
+    uint64_t* rows = hot_rows_of(A);
+    if (rows && tid < HOTW) {
+        const uint64_t imax2 = ((uint64_t)(uint32_t)INT32_MAX << 32) | (uint32_t)INT32_MAX;
+        rows[(uint64_t)blockIdx.x * HOTW + tid] = tid < NSUM ? 0ull : imax2;
+    }
+}
+
+// HOT = false compiles the hot-row path out (the fused adjacency kernels sit on the edge of their register
+// budget: any extra code, even here in the epilogue, tips their allocation from 1 into ~100 spilled registers).
+template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS>
 __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const int tid, const uint64_t A0,
-                                             const uint64_t B0, const uint64_t C0) {
+                                             const uint64_t B0, const uint64_t C0, const uint32_t hot) {
+    uint64_t* const hot_rows = HOT ? hot_rows_of(A) : nullptr;
     for (int i = tid; i < LSLOTS; i += WAVES * 64) {
         const uint32_t label = S.lkeys[i];
         if (label == INVALID_LABEL) continue;
@@ -226,10 +251,13 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
         }
         uint64_t g[NSUM];
         local_to_global(L, A0, B0, C0, g);
-        unsigned long long* row = (unsigned long long*)&A.sums[(uint64_t)label * NSUM];
+        // the hot label goes to this workgroup's private row: same atomics, nobody to contend with
+        const bool priv = HOT && hot_rows && label == hot;
+        uint64_t* hr = hot_rows + (uint64_t)blockIdx.x * HOTW;
+        unsigned long long* row = (unsigned long long*)(priv ? hr : &A.sums[(uint64_t)label * NSUM]);
 #pragma unroll
         for (int k = 0; k < (MOM2 ? NSUM : 4); ++k) atomicAdd(row + k, (unsigned long long)g[k]);
-        int32_t* box = &A.boxes[(uint64_t)label * NBOX];
+        int32_t* box = priv ? reinterpret_cast<int32_t*>(hr + NSUM) : &A.boxes[(uint64_t)label * NBOX];
         atomicMin(box + 0, (int32_t)(A0 + S.lbox[i * 8 + 0])); atomicMin(box + 3, -(int32_t)(A0 + S.lbox[i * 8 + 3]));
         atomicMin(box + 1, (int32_t)(B0 + S.lbox[i * 8 + 1])); atomicMin(box + 4, -(int32_t)(B0 + S.lbox[i * 8 + 4]));
         atomicMin(box + 2, (int32_t)(C0 + S.lbox[i * 8 + 2])); atomicMin(box + 5, -(int32_t)(C0 + S.lbox[i * 8 + 5]));
