@@ -165,6 +165,18 @@ TA_API int ta_volume_get(ta_ctx* ctx, void* host_dst);
 TA_API int ta_volume_map(ta_ctx* ctx, const void* lut, uint32_t lut_len, const void* fill, int out_itemsize,
                          void* host_dst);
 
+/* ---- wall voxels ------------------------------------------------------------
+ * A voxel p of label l is a wall voxel of the pair (l, m) when one of its 18 neighbours (faces and
+ * edges: scipy generate_binary_structure(3, 2), SIA:796-799) carries a label m != l; this is
+ * (dil(mask_l) & mask_m) | (dil(mask_m) & mask_l) of wall_voxels_between_two_cells (SIA:759-806)
+ * for every pair at once.  ta_wall_voxels_count runs the counting pass and returns the number of
+ * (pair, voxel) records; ta_wall_voxels_get runs the emit pass and fills caller-allocated arrays of
+ * that length: lo < hi labels and the voxel's coordinates in ARRAY-axis order, records ordered by the
+ * voxel's position in memory (for a C-ordered array: np.where order).  ms (optional) receives the
+ * duration of the two kernels.  Not available on a slab with a halo plane. */
+TA_API int ta_wall_voxels_count(ta_ctx* ctx, int64_t* nrecords);
+TA_API int ta_wall_voxels_get(ta_ctx* ctx, uint32_t* lo, uint32_t* hi, int32_t* coords /* [n][3] */, double* ms);
+
 /* ---- stream-ordered adjacency exchange (no host round trip) ------------------
  * One exchange block per rank, uint64 words, TA_EXCHANGE_WORDS(capacity) long:
  *   [0] pair count (may exceed capacity)  [1] status bits  [2..2+cap) keys, ~0 padded

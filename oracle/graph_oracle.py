@@ -71,4 +71,45 @@ def graph_tables(image, labels=None, background=1, properties=None, property_as_
     if "epidermis_surface" in properties:                                                              # TGI:197-208
         areas = analysis.cell_wall_area(background, list(background_neighbors), real=property_as_real)
         V["epidermis_surface"] = dict(((b if a == background else a), v) for (a, b), v in areas.items())
+    if "wall_median" in properties:                                                                    # TGI:210-242
+        walls = analysis.wall_voxels_per_cells_pairs(list(labels), dict((k, list(v)) for k, v in neighborhood.items()),
+                                                     ignore_background=False)
+        median = {}
+        for pair, (x, y, z) in walls.items():
+            origin = np.array([int(v) for v in weiszfeld(np.array([list(x), list(y), list(z)], dtype=float))])
+            pts = np.array([x, y, z]).T
+            d = ((pts - origin) ** 2).sum(axis=1)
+            median[pair] = tuple(int(v) for v in pts[int(np.argmin(d))])    # closest_from_A: third-party, absent (assumed)
+        E["wall_median"] = dict((p, m) for p, m in median.items() if p[0] in labelset and p[1] in labelset)
+        V["unlabelled_wall_median"] = dict((p[1], m) for p, m in median.items() if p[0] == 0)
+        V["epidermis_wall_median"] = dict((p[1], m) for p, m in median.items() if p[0] == 1)
     return out
+
+
+def weiszfeld(X, numIter=200):
+    """geometric_median as written in SIA:1586-1635 (point-by-point loops)."""
+    import math
+    y = np.mean(X, 1)
+    while (y[0] in X[0]) and (y[1] in X[1]) and (y[2] in X[2]):
+        y += 0.1
+    convergence, dist, i = False, [], 0
+    while (not convergence) and (i < numIter):
+        num_x = num_y = num_z = denum = 0.0
+        d = 0
+        for j in range(X.shape[1]):
+            div = math.sqrt((X[0, j] - y[0]) ** 2 + (X[1, j] - y[1]) ** 2 + (X[2, j] - y[2]) ** 2)
+            num_x += X[0, j] / div
+            num_y += X[1, j] / div
+            num_z += X[2, j] / div
+            denum += 1. / div
+            d += div ** 2
+        dist.append(d)
+        if denum == 0.:
+            return [0, 0, 0]
+        y = [num_x / denum, num_y / denum, num_z / denum]
+        if i > 3:
+            convergence = (abs(dist[i] - dist[i - 2]) < 0.1)
+        i += 1
+    if i == numIter:
+        raise ValueError("The Weiszfeld's algoritm did not converged")
+    return np.array(y)

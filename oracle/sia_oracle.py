@@ -433,6 +433,64 @@ class OracleSIA(object):
         return tuple(slice(a, b) for a, b in zip(starts, stops))
 
 
+    # -- wall voxels (SIA:759-880, 1049-1111), as written: crops, two masks, 18-connectivity dilations
+    def wall_voxels_between_two_cells(self, label_1, label_2):  # SIA:759-806 (bbox given as the dict of boxes)
+        b1, b2 = self.boundingbox(label_1), self.boundingbox(label_2)
+        if b1 is None or b2 is None:
+            return np.zeros((3, 0), dtype=np.int64)
+        vol = lambda b: np.prod([s.stop - s.start for s in b])
+        box = b1 if vol(b1) < vol(b2) else b2                      # sort_boundingbox, SIA:97-112
+        dil = dilate_slices(box)
+        crop = np.asarray(self.image)[dil]
+        m1, m2 = crop == label_1, crop == label_2
+        struct = nd.generate_binary_structure(3, 2)
+        d1, d2 = nd.binary_dilation(m1, structure=struct), nd.binary_dilation(m2, structure=struct)
+        x, y, z = np.where((d1 & m2) | (d2 & m1))
+        return np.array((x + dil[0].start, y + dil[1].start, z + dil[2].start))
+
+    def wall_voxels_per_cell(self, label_1, neighbors=None, neighbors2ignore=()):  # SIA:809-880
+        box = self.boundingbox(label_1)
+        dil = dilate_slices(dilate_slices(box))
+        crop = np.asarray(self.image)[dil]
+        m1 = crop == label_1
+        struct = nd.generate_binary_structure(3, 2)
+        d1 = nd.binary_dilation(m1, structure=struct)
+        if neighbors is None:
+            neighbors = self.neighbors(label_1)
+        if isinstance(neighbors, (int, np.integer)):
+            neighbors = [neighbors]
+        neighbors = [n for n in neighbors if n not in neighbors2ignore]
+        coord = {}
+        for label_2 in neighbors:
+            m2 = crop == label_2
+            d2 = nd.binary_dilation(m2, structure=struct)
+            x, y, z = np.where((d1 & m2) | (d2 & m1))
+            if len(x):
+                coord[min(label_1, label_2), max(label_1, label_2)] = np.array(
+                    (x + dil[0].start, y + dil[1].start, z + dil[2].start))
+        return coord
+
+    def wall_voxels_per_cells_pairs(self, labels=None, neighborhood=None, ignore_background=False,
+                                    min_contact_area=None, real_area=True):  # SIA:1049-1111
+        compute = neighborhood is None
+        if isinstance(labels, list) and isinstance(neighborhood, dict):
+            labels = [l for l in labels if l in neighborhood]
+        if labels is None:
+            labels = self.labels()
+        elif isinstance(labels, list):
+            labels.sort()
+        else:
+            labels = [labels]
+        out = {}
+        for label in labels:
+            neighbors = list(self.neighbors(label, min_contact_area, real_area)) if compute else list(neighborhood[label])
+            keep = labels if ignore_background else labels + [self._background]
+            ignore = [n for n in neighbors if n not in keep]
+            neighbors = [n for n in neighbors if (min(label, n), max(label, n)) not in out]
+            if neighbors:
+                out.update(self.wall_voxels_per_cell(label, neighbors, ignore))
+        return out
+
     # -- image mutation (SIA:1114-1176), as written: per-label bounding-box crops, image edited in place;
     # the bounding boxes are the ones cached at construction (the reference never refreshes them)
     def fuse_labels_in_image(self, labels, verbose=False):  # SIA:1114-1136

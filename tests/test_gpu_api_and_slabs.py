@@ -214,7 +214,8 @@ def test_graph_from_image_end_to_end_on_gpu():
     from oracle import graph_oracle
     from tissue_analysis_amd import graph_from_image, property_graph_to_dataframe
     from graph_compare import compare_graph
-    props = ['boundingbox', 'volume', 'barycenter', 'L1', 'border', 'inertia_axis', 'wall_surface', 'epidermis_surface']
+    props = ['boundingbox', 'volume', 'barycenter', 'L1', 'border', 'inertia_axis', 'wall_surface', 'epidermis_surface',
+             'wall_median']
     vol = voronoi((48, 40, 72), 60, 41, np.uint16)
     img = SpatialImage(vol, voxelsize=synth.PARITY_VOXELSIZE)
     g = graph_from_image(img, spatio_temporal_properties=list(props), min_contact_area=2.0)

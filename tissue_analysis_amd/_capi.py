@@ -25,6 +25,7 @@ SYMBOLS = (
     "ta_version", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_get_option", "ta_ctx_synchronize", "ta_volume_set",
     "ta_volume_set_device", "ta_volume_max_label", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
+    "ta_wall_voxels_count", "ta_wall_voxels_get",
     "ta_extract", "ta_get_labels",
     "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_debug_counters", "ta_bind_accumulators",
     "ta_accumulators_device", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge",
@@ -76,6 +77,8 @@ def load():
         "ta_volume_relabel": (ci, [vp, vp, u32]),
         "ta_volume_get": (ci, [vp, vp]),
         "ta_volume_map": (ci, [vp, vp, u32, vp, ci, vp]),
+        "ta_wall_voxels_count": (ci, [vp, P(i64)]),
+        "ta_wall_voxels_get": (ci, [vp, vp, vp, vp, P(ctypes.c_double)]),
         "ta_extract": (ci, [vp, u32, u32]),
         "ta_get_labels": (ci, [vp, vp, vp, vp, vp]),
         "ta_adjacency_size": (ci, [vp, P(i64)]),
@@ -222,6 +225,19 @@ class Context(object):
                                        ctypes.c_void_p(fillv.ctypes.data), int(lut.dtype.itemsize),
                                        ctypes.c_void_p(out.ctypes.data)))
         return out
+
+    def wall_voxels(self):
+        """All (pair, wall voxel) records of the resident volume: lo u32[n], hi u32[n], coords i32[n,3]
+        (array-axis order), ordered by the voxel's position in memory; plus the kernels' milliseconds."""
+        n = ctypes.c_int64(0)
+        _check(self._lib.ta_wall_voxels_count(self._h, ctypes.byref(n)))
+        lo = np.zeros(n.value, dtype=np.uint32)
+        hi = np.zeros(n.value, dtype=np.uint32)
+        coords = np.zeros((n.value, 3), dtype=np.int32)
+        ms = ctypes.c_double(0.0)
+        _check(self._lib.ta_wall_voxels_get(self._h, lo.ctypes.data, hi.ctypes.data, coords.ctypes.data,
+                                            ctypes.byref(ms)))
+        return lo, hi, coords, ms.value
 
     def set_volume_device(self, dev_ptr, itemsize, buf_dims, a0_origin=0, has_low_halo=False, keep=None):
         _check(self._lib.ta_volume_set_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(itemsize),

@@ -79,6 +79,9 @@ struct ta_ctx {
     DevBuf pkeys, pfaces, out_keys, out_faces, small;   // small: flags[NFLAGS] | cursor | maxlabel
     DevBuf split_f, split_r, split_hdr;                 // record regions of the split path (TA_OPT_IMPL = 2)
     DevBuf hot_rows;                                    // [workgroups][16] private rows of the hot label
+    DevBuf wall_counts;                                 // wall voxels: per-chunk record counts, then offsets
+    int64_t wall_records = -1;                          // result of the last ta_wall_voxels_count, -1 = none
+    double wall_ms = 0.0;
     bool split_failed = false;                          // a region overflowed on this volume: use the fused sweep
     int pair_log2 = 0;                                  // current table log2 capacity
     int opt_pair_log2 = 0;
@@ -299,6 +302,7 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     c->pkeys.release(); c->pfaces.release(); c->out_keys.release(); c->out_faces.release();
     c->small.release();
     c->split_f.release(); c->split_r.release(); c->split_hdr.release(); c->hot_rows.release();
+    c->wall_counts.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -389,6 +393,7 @@ TA_API int ta_volume_set(ta_ctx* c, const void* host_ptr, int itemsize, const in
     TA_HIP(hipStreamSynchronize(c->stream));   // the host buffer may be freed after return
     c->vol = c->owned_vol.p;
     c->split_failed = false;
+    c->wall_records = -1;
     c->itemsize = itemsize;
     for (int k = 0; k < 3; ++k) { c->perm[k] = perm[k]; c->mdims[k] = dims[perm[k]]; }
     c->a_origin = 0;
@@ -408,6 +413,7 @@ TA_API int ta_volume_set_device(ta_ctx* c, const void* dev_ptr, int itemsize, co
     if (((uintptr_t)dev_ptr % itemsize) != 0) return fail(TA_EINVAL, "device pointer is not aligned to the label type");
     c->vol = dev_ptr;
     c->split_failed = false;
+    c->wall_records = -1;
     c->itemsize = itemsize;
     for (int k = 0; k < 3; ++k) { c->perm[k] = k; c->mdims[k] = buf_dims[k]; }
     c->a_origin = a0_origin;
@@ -477,6 +483,80 @@ TA_API int ta_volume_map(ta_ctx* c, const void* lut, uint32_t lut_len, const voi
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     dl.release(); dout.release();
     if (e != hipSuccess) return fail(TA_EHIP, "map: %s", hipGetErrorString(e));
+    return TA_OK;
+}
+
+TA_API int ta_wall_voxels_count(ta_ctx* c, int64_t* nrecords) {
+    if (!c || !nrecords) return fail(TA_EINVAL, "NULL argument");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    if (c->first_owned) return fail(TA_EINVAL, "wall voxels are not available on a slab that carries a halo plane");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t chunks = ta::wall_chunks(c->mdims[0], c->mdims[1], c->mdims[2]);
+    if ((rc = c->wall_counts.reserve(chunks * 8 + 8)) != TA_OK) return rc;
+    hipEvent_t e0, e1;
+    TA_HIP(hipEventCreate(&e0)); TA_HIP(hipEventCreate(&e1));
+    TA_HIP(hipEventRecord(e0, c->stream));
+    ta::launch_wall_count(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], (uint64_t*)c->wall_counts.p);
+    TA_HIP(hipEventRecord(e1, c->stream));
+    std::vector<uint64_t> h(chunks + 1, 0);
+    TA_HIP(hipMemcpyAsync(h.data(), c->wall_counts.p, chunks * 8, hipMemcpyDeviceToHost, c->stream));
+    TA_HIP(hipStreamSynchronize(c->stream));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    uint64_t run = 0;                                        // exclusive scan of the chunk counts
+    for (uint64_t k = 0; k < chunks; ++k) { const uint64_t n = h[k]; h[k] = run; run += n; }
+    TA_HIP(hipMemcpyAsync(c->wall_counts.p, h.data(), chunks * 8, hipMemcpyHostToDevice, c->stream));
+    TA_HIP(hipStreamSynchronize(c->stream));
+    c->wall_records = (int64_t)run;
+    c->wall_ms = ms;
+    *nrecords = c->wall_records;
+    return TA_OK;
+}
+
+TA_API int ta_wall_voxels_get(ta_ctx* c, uint32_t* lo, uint32_t* hi, int32_t* coords, double* ms_out) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if (c->wall_records < 0) return fail(TA_EINVAL, "call ta_wall_voxels_count first");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t n = (uint64_t)c->wall_records;
+    if (ms_out) *ms_out = c->wall_ms;
+    if (n == 0) return TA_OK;
+    if (!lo || !hi || !coords) return fail(TA_EINVAL, "NULL output array");
+    DevBuf dk, di;
+    if ((rc = dk.reserve(n * 8)) != TA_OK) return rc;
+    if ((rc = di.reserve(n * 8)) != TA_OK) { dk.release(); return rc; }
+    std::vector<uint64_t> hk, hi64;
+    try { hk.resize(n); hi64.resize(n); } catch (...) { dk.release(); di.release(); return fail(TA_ENOMEM, "out of host memory"); }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    if (e == hipSuccess) {
+        ta::launch_wall_emit(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2],
+                             (const uint64_t*)c->wall_counts.p, (uint64_t*)dk.p, (uint64_t*)di.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hk.data(), dk.p, n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(hi64.data(), di.p, n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    float ms = 0.f;
+    if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    dk.release(); di.release();
+    if (e != hipSuccess) return fail(TA_EHIP, "wall voxels: %s", hipGetErrorString(e));
+    if (ms_out) *ms_out = c->wall_ms + ms;
+    const int64_t n1 = c->mdims[1], n2 = c->mdims[2];
+    for (uint64_t r = 0; r < n; ++r) {
+        lo[r] = (uint32_t)(hk[r] >> 32);
+        hi[r] = (uint32_t)(hk[r] & 0xffffffffu);
+        const int64_t i = (int64_t)hi64[r], a = i / (n1 * n2), rem = i - a * n1 * n2;
+        const int64_t m[3] = {a, rem / n2, rem % n2};
+        for (int k = 0; k < 3; ++k) coords[3 * r + c->perm[k]] = (int32_t)m[k];
+    }
     return TA_OK;
 }
 

@@ -22,6 +22,11 @@ void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const ui
 void launch_relabel(hipStream_t s, void* vol, int itemsize, uint64_t n, const uint32_t* lut, uint32_t lut_len);
 void launch_map(hipStream_t s, const void* vol, int itemsize, void* out, int out_itemsize, uint64_t n,
                 const void* lut, uint32_t lut_len, uint64_t fill);
+uint64_t wall_chunks(int64_t n0, int64_t n1, int64_t n2);
+void launch_wall_count(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2,
+                       uint64_t* chunk_counts);
+void launch_wall_emit(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2,
+                      const uint64_t* chunk_offsets, uint64_t* out_keys, uint64_t* out_index);
 void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3], int64_t a_begin,
                   int64_t a_count, const int32_t* seeds_dev, const int32_t grid[3],
                   const int64_t* ell_dev);

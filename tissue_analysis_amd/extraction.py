@@ -213,3 +213,56 @@ def map_volume(array, lut, fill, device=0):
     finally:
         ctx.close()
     return out[:, :, 0] if flat else out
+
+
+class WallTable(object):
+    """Wall voxels of every label pair of one image (SIA:759-880), from one GPU pass: records sorted by
+    pair, each pair's voxels in np.where order of the image (lexicographic in the array axes)."""
+
+    def __init__(self, lo, hi, coords, ms=None):
+        key = (lo.astype(np.uint64) << np.uint64(32)) | hi.astype(np.uint64)
+        order = np.argsort(key, kind="stable")
+        self.key = key[order]
+        self.coords = coords[order]
+        self.ms = ms
+        if self.key.size:
+            cut = np.flatnonzero(self.key[1:] != self.key[:-1]) + 1
+            self.start = np.concatenate([[0], cut])
+            self.stop = np.concatenate([cut, [self.key.size]])
+            self.pairs = self.key[self.start]
+        else:
+            self.start = self.stop = np.zeros(0, dtype=np.int64)
+            self.pairs = np.zeros(0, dtype=np.uint64)
+
+    def __len__(self):
+        return int(self.pairs.size)
+
+    def between(self, label_1, label_2):
+        """(3, N) int64 coordinates of the wall voxels between the two labels (N = 0 when they do not touch)."""
+        a, b = (int(label_1), int(label_2)) if label_1 < label_2 else (int(label_2), int(label_1))
+        k = np.uint64((a << 32) | b)
+        i = int(np.searchsorted(self.pairs, k))
+        if i >= self.pairs.size or self.pairs[i] != k:
+            return np.zeros((3, 0), dtype=np.int64)
+        return np.ascontiguousarray(self.coords[self.start[i]:self.stop[i]].T).astype(np.int64)
+
+
+def wall_voxel_table(array, device=0):
+    """Upload `array` and extract the wall voxels of all label pairs (18-neighbourhood) on the GPU."""
+    a = np.asarray(array)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    if a.dtype not in (np.uint16, np.uint32):
+        wide = a.size and int(a.max()) > 65535
+        a = np.ascontiguousarray(a, dtype=np.uint32 if wide else np.uint16)
+    c_order = a.flags.c_contiguous
+    ctx = _capi.Context(device)
+    try:
+        ctx.set_volume(a)
+        lo, hi, coords, ms = ctx.wall_voxels()
+    finally:
+        ctx.close()
+    if not c_order and coords.shape[0]:          # records come in memory order: put them in np.where order
+        order = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
+        lo, hi, coords = lo[order], hi[order], coords[order]
+    return WallTable(lo, hi, coords, ms)

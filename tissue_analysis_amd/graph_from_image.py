@@ -10,14 +10,17 @@ Reference behaviour kept as written (and pinned by tests against ``oracle/graph_
     slot: real-unit eigenvalues iff 'barycenter' was requested before.
   * 'epidermis_surface' calls `analysis.cell_wall_surface` (TGI:197), which the reference class does
     not define (AttributeError there); here it is `cell_wall_area(background, ...)`, its evident intent.
-Out of scope for now: 'wall_median' needs the wall-voxel extraction of §8f-3 (and a geometric
-median from `openalea.image.algo.analysis`, absent): requesting it raises NotImplementedError, and it
-is left out of the default property list (the reference's default includes it).
+  * 'wall_median' (TGI:210-242): wall voxels of every pair from the one-pass GPU extraction
+    (`wall_voxels_per_cells_pairs`), their geometric median by the reference's own Weiszfeld iteration
+    (SIA:1586-1635) truncated to integers, then the wall voxel closest to it (`closest_from_A`, an absent
+    third-party helper restated in geometry.py); keys with label 0 / 1 go to 'unlabelled_wall_median' /
+    'epidermis_wall_median' as in the reference.
 """
 from __future__ import annotations
 
 import numpy as np
 
+from .geometry import closest_from_A, geometric_median
 from .property_graph import PropertyGraph
 from .spatial_image_analysis import AbstractSpatialImageAnalysis, DICT, SpatialImageAnalysis
 
@@ -50,7 +53,7 @@ def availables_properties():  # TGI:70-74
 
 
 spatio_temporal_properties2D = ['barycenter', 'boundingbox', 'border', 'L1', 'epidermis_area', 'inertia_axis']
-spatio_temporal_properties3D = [p for p in availables_properties() if p != 'wall_median']
+spatio_temporal_properties3D = availables_properties()
 
 
 def label2vertex_map(graph, time_point=None):
@@ -139,8 +142,6 @@ def _graph_from_image(image, labels, background, default_properties, property_as
             analysis = SpatialImageAnalysis(image, ignoredlabels=0, return_type=DICT, background=1)
         except Exception:
             analysis = SpatialImageAnalysis(image, ignoredlabels=0, return_type=DICT)
-    if 'wall_median' in default_properties:
-        raise NotImplementedError("'wall_median' needs the wall-voxel extraction (SURVEY.md §8f-3), not built yet")
     if ignore_cells_at_stack_margins:
         analysis.add2ignoredlabels(analysis.labels_at_stack_margins())
 
@@ -207,6 +208,28 @@ def _graph_from_image(image, labels, background, default_properties, property_as
         epidermis = analysis.cell_wall_area(background, list(background_neighbors), real=property_as_real)
         epidermis = dict(((b if a == background else a), v) for (a, b), v in epidermis.items())
         add_vertex_property_from_label_property(graph, 'epidermis_surface', epidermis, mlabel2vertex=label2vertex)
+
+    if 'wall_median' in default_properties:  # TGI:210-242
+        dict_wall_voxels = analysis.wall_voxels_per_cells_pairs(labels, neighborhood, ignore_background=False,
+                                                                verbose=False)
+        wall_median = {}
+        for (label_1, label_2), (x, y, z) in dict_wall_voxels.items():
+            origin = np.array([int(v) for v in geometric_median(np.array([list(x), list(y), list(z)]))])
+            pts = [(int(x[i]), int(y[i]), int(z[i])) for i in range(len(x))]
+            wall_median[(label_1, label_2)] = closest_from_A(origin, pts)
+        edge_wall_median, unlabelled_wall_median, vertex_wall_median = {}, {}, {}
+        vertices = set(graph.vertices())
+        for label_1, label_2 in dict_wall_voxels.keys():
+            if (label_1 in vertices) and (label_2 in vertices):
+                edge_wall_median[(label_1, label_2)] = wall_median[(label_1, label_2)]
+            if label_1 == 0:
+                unlabelled_wall_median[label_2] = wall_median[(label_1, label_2)]
+            if label_1 == 1:
+                vertex_wall_median[label_2] = wall_median[(label_1, label_2)]
+        add_edge_property_from_dictionary(graph, 'wall_median', edge_wall_median, mlabelpair2edge=edges)
+        add_vertex_property_from_dictionary(graph, 'epidermis_wall_median', vertex_wall_median, mlabel2vertex=label2vertex)
+        add_vertex_property_from_dictionary(graph, 'unlabelled_wall_median', unlabelled_wall_median,
+                                            mlabel2vertex=label2vertex)
     return graph
 
 

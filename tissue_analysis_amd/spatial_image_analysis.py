@@ -90,6 +90,7 @@ class AbstractSpatialImageAnalysis(object):
         self._neighbors = None
         self._cell_layer1 = None
         self._center_of_mass = {}
+        self._walls = None
         try:
             self.filepath, self.filename = split(image.info["Filename"])
         except Exception:
@@ -127,6 +128,7 @@ class AbstractSpatialImageAnalysis(object):
         self._neighbors = None
         self._cell_layer1 = None
         self._center_of_mass = {}
+        self._walls = None
 
     @property
     def extraction(self):
@@ -369,6 +371,79 @@ class AbstractSpatialImageAnalysis(object):
         return self._cell_layer2
 
 
+    # -- wall voxels (SIA:759-880, 1049-1111): one GPU pass finds the wall voxels of EVERY pair (18-neighbourhood
+    # contact, scipy's generate_binary_structure(3, 2)); the methods below are lookups in that table.
+    def wall_table(self):
+        if self._walls is None:
+            from .extraction import wall_voxel_table
+            self._walls = wall_voxel_table(np.asarray(self.image), device=self._device)
+        return self._walls
+
+    def wall_voxels_between_two_cells(self, label_1, label_2, bbox=None, verbose=False):  # SIA:759-806
+        """3xN array of the voxel coordinates of the contact wall between two labels (np.where order)."""
+        return self.wall_table().between(label_1, label_2)
+
+    def wall_voxels_per_cell(self, label_1, bbox=None, neighbors=None, neighbors2ignore=[], verbose=False):  # SIA:809-880
+        if neighbors is None:
+            neighbors = self.neighbors(label_1)
+        if isinstance(neighbors, _INT):
+            neighbors = [neighbors]
+        if isinstance(neighbors, dict) and len(neighbors) != 1:
+            neighbors = copy.copy(neighbors[label_1])
+        if neighbors2ignore != []:
+            for nei in neighbors2ignore:
+                try:
+                    neighbors.remove(nei)
+                except ValueError:
+                    pass
+        coord = {}
+        neighbors_not_found = []
+        for label_2 in neighbors:
+            xyz = self.wall_table().between(label_1, label_2)
+            if xyz.shape[1]:
+                coord[min(label_1, label_2), max(label_1, label_2)] = xyz
+            else:
+                neighbors_not_found.append(label_2)
+        if neighbors_not_found:
+            print("Some walls have not been found comparing to the `neighbors` list of {}: {}".format(
+                label_1, neighbors_not_found))
+        return coord
+
+    def wall_voxels_per_cells_pairs(self, labels=None, neighborhood=None, only_epidermis=False,
+                                    ignore_background=False, min_contact_area=None, real_area=True,
+                                    verbose=True):  # SIA:1049-1111
+        if only_epidermis:
+            raise NotImplementedError("only_epidermis needs voxel_first_layer (SIA:1024-1046), which is not built")
+        compute_neighborhood = neighborhood is None
+        if isinstance(labels, list) and isinstance(neighborhood, dict):
+            labels = [label for label in labels if label in neighborhood]
+        if labels is None:
+            labels = self.labels()
+        elif isinstance(labels, list):
+            labels.sort()
+            if not isinstance(neighborhood, dict):
+                compute_neighborhood = True
+        elif isinstance(labels, _INT):
+            labels = [labels]
+        else:
+            raise ValueError("Couldn't find any labels.")
+        dict_wall_voxels = {}
+        for label in labels:
+            if compute_neighborhood:
+                neighbors = self.neighbors(label, min_contact_area, real_area)
+            elif isinstance(neighborhood, dict):
+                neighbors = copy.copy(neighborhood[label])
+            else:
+                neighbors = neighborhood
+            if ignore_background:
+                neighbors2ignore = [n for n in neighbors if n not in labels]
+            else:
+                neighbors2ignore = [n for n in neighbors if n not in labels + [self.background()]]
+            neighbors = [n for n in neighbors if (min(label, n), max(label, n)) not in dict_wall_voxels]
+            if neighbors != []:
+                dict_wall_voxels.update(self.wall_voxels_per_cell(label, None, neighbors, neighbors2ignore, verbose=False))
+        return dict_wall_voxels
+
     # -- image mutation (SIA:1114-1176): one lookup-table sweep on the GPU instead of per-label crops.
     # The reference leaves its caches (_labels, _bbox, _neighbors ...) stale after these calls; here the
     # relabelled volume is swept again in the same upload, so every later answer describes the new image.
@@ -396,6 +471,7 @@ class AbstractSpatialImageAnalysis(object):
         self._neighbors = None
         self._cell_layer1 = None
         self._center_of_mass = {}
+        self._walls = None
 
     def fuse_labels_in_image(self, labels, verbose=True):  # SIA:1114-1136
         """Modify the image so the given labels are fused (to the min value)."""
