@@ -143,6 +143,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if n > 1:                       # one-off size agreement of every job in flight (synchronous), before any timing
+        for _ in range(depth):
+            job.step()
+        job.finish()
     for _ in range(args.warmup):
         job.step()
     barrier()
