@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default=None, help="override: C2/C3/C4/C5 on one GPU")
+    ap.add_argument("--features", type=lambda v: int(v, 0), default=None,
+                    help="override the feature mask (e.g. 0x0f = everything but adjacency); not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--tile-planes", type=int, default=0)
     ap.add_argument("--dims", type=int, nargs=3, default=None, help="rehearsal: override the volume shape")
@@ -112,6 +114,9 @@ def main():
     else:
         cfg = weak_config(n)
         feats = _capi.F_ALL
+    if args.features is not None:
+        feats = args.features
+        cfg = dict(cfg, name=cfg["name"] + "-mask0x%02x" % feats)
     if args.dims:
         cfg = dict(cfg, dims=tuple(args.dims), name=cfg["name"] + "-custom")
     dims, dtype = cfg["dims"], np.dtype(cfg["dtype"])
