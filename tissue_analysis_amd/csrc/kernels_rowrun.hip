@@ -35,39 +35,6 @@ struct __attribute__((aligned(16))) RowLds {
     uint32_t pcnt[PSLOTS * 3];
 };
 
-// inclusive max-scan over the 64 lanes (identity 0): row_shr 1,2,4,8 then the two row broadcasts
-__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
-#define TA_DPP_MAX(ctrl, rmask)                                                                   \
-    { const uint32_t y_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, false); \
-      x = x > y_ ? x : y_; }
-    TA_DPP_MAX(0x111, 0xf) TA_DPP_MAX(0x112, 0xf) TA_DPP_MAX(0x114, 0xf) TA_DPP_MAX(0x118, 0xf)
-    TA_DPP_MAX(0x142, 0xa) TA_DPP_MAX(0x143, 0xc)
-#undef TA_DPP_MAX
-    return x;
-}
-
-// one run [c0, c0+n) of a row (tile-local a, b): ten sums, every term < 2^32, every factor < 2^24
-template <bool MOM2, typename LDS>
-__device__ __forceinline__ void consume_row_run(const SweepArgs& A, LDS& S, const TileFrame& F, uint32_t label,
-                                                uint32_t code) {
-    const uint32_t c0 = code & 511u, n = (code >> 9) & 1023u, bl = (code >> 19) & 15u, al = (code >> 23) & 63u;
-    if (label >= LABEL_LIMIT || n == 0u) return;
-    const uint32_t t1 = __umul24(n, n - 1u);                                 // n (n - 1), even
-    const uint32_t nc0 = __umul24(n, c0);
-    const uint32_t sc = nc0 + (t1 >> 1);                                     // sum c over the run
-    const uint32_t na = __umul24(n, al), nb = __umul24(n, bl);
-    RunSums L;
-    L.n = n; L.sa = na; L.sb = nb; L.sc = sc;
-    if (MOM2) {
-        L.saa = __umul24(na, al); L.sab = __umul24(na, bl); L.sbb = __umul24(nb, bl);
-        L.sac = __umul24(al, sc); L.sbc = __umul24(bl, sc);
-        L.scc = __umul24(nc0, c0) + __umul24(c0, t1) + __umul24(t1 >> 1, 2u * n - 1u) / 3u;
-    } else {
-        L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
-    }
-    lds_label_add<MOM2, LDS, RunSums>(A, S, F, label, L, al, al, bl, bl, c0, c0 + n - 1u);
-}
-
 template <bool ADJ, bool MOM2, typename LDS>
 __device__ __forceinline__ void consume_row_rings(const SweepArgs& A, LDS& S, const TileFrame& F, int w, int lane,
                                                   int& fhead, int ftail, int& chead, int ctail, bool all) {

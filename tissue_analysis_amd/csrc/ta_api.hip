@@ -79,6 +79,7 @@ struct ta_ctx {
     DevBuf pkeys, pfaces, out_keys, out_faces, small;   // small: flags[NFLAGS] | cursor | maxlabel
     DevBuf split_f, split_r, split_hdr;                 // record regions of the split path (TA_OPT_IMPL = 2)
     DevBuf hot_rows;                                    // [workgroups][16] private rows of the hot label
+    DevBuf rle_rec, rle_dir, rle_hdr;                   // RLE path (TA_OPT_IMPL = 5): run records, row directory, counts
     DevBuf wall_counts;                                 // wall voxels: per-chunk record counts, then offsets
     int64_t wall_records = -1;                          // result of the last ta_wall_voxels_count, -1 = none
     double wall_ms = 0.0;
@@ -163,7 +164,8 @@ int run_extract(ta_ctx* c) {
     uint64_t* hot_rows = nullptr;
     uint64_t nwg = 0;
     const bool rowrun = c->impl == 3 || (c->impl == 0 && !(c->feature_mask & TA_F_ADJACENCY));
-    if (rowrun && !(c->feature_mask & TA_F_ADJACENCY)) {     // the kernels that use the private hot-label rows
+    const bool rle = c->impl == 5 && !c->split_failed && c->first_owned == 0;
+    if ((rowrun && !(c->feature_mask & TA_F_ADJACENCY)) || rle) {     // the kernels that use the private hot-label rows
         nwg = ta::sweep_grid_size(a, c->itemsize);
         int rc0 = c->hot_rows.reserve(nwg * ta::HOTW * 8);
         if (rc0 != TA_OK) return rc0;
@@ -191,6 +193,17 @@ int run_extract(ta_ctx* c) {
         if ((rc = c->split_hdr.reserve(wave_tiles * 16)) != TA_OK) return rc;
         sa.frec = (uint64_t*)c->split_f.p; sa.rrec = (uint64_t*)c->split_r.p; sa.rhdr = (uint32_t*)c->split_hdr.p;
         ta::launch_split(c->stream, sa, c->itemsize, c->feature_mask);
+    } else if (rle) {
+        ta::RleArgs ra;
+        ra.a = a;
+        uint64_t wave_tiles = 0; uint32_t drows = 0;
+        ta::rle_region_shape(a, c->itemsize, &wave_tiles, &ra.rcap, &drows);
+        int rc;
+        if ((rc = c->rle_rec.reserve(wave_tiles * 3ull * ra.rcap * 4)) != TA_OK) return rc;
+        if ((rc = c->rle_dir.reserve(wave_tiles * (uint64_t)drows * 16)) != TA_OK) return rc;
+        if ((rc = c->rle_hdr.reserve(wave_tiles * 4 + 16)) != TA_OK) return rc;
+        ra.rle = (uint32_t*)c->rle_rec.p; ra.dir = (uint4*)c->rle_dir.p; ra.hdr = (uint32_t*)c->rle_hdr.p;
+        ta::launch_rle(c->stream, ra, c->itemsize, c->feature_mask);
     } else if (c->impl == 3 || (c->impl == 0 && !adj)) {
         // default: runs along the contiguous axis when no adjacency is asked for (moments-only sets run
         // at 55-60 % of the HBM peak there), the fused axis-0 sweep when it is (equal on C4, faster on C3)
@@ -303,6 +316,7 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     c->small.release();
     c->split_f.release(); c->split_r.release(); c->split_hdr.release(); c->hot_rows.release();
     c->wall_counts.release();
+    c->rle_rec.release(); c->rle_dir.release(); c->rle_hdr.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -330,7 +344,7 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
     if (!c) return fail(TA_EINVAL, "ctx is NULL");
     switch (key) {
         case TA_OPT_IMPL:
-            if (value < 0 || value > 4) return fail(TA_EINVAL, "TA_OPT_IMPL must be in [0,4]");
+            if (value < 0 || value > 5) return fail(TA_EINVAL, "TA_OPT_IMPL must be in [0,5]");
             c->impl = (int)value; return TA_OK;
         case TA_OPT_TILE_PLANES:
             if (value < 0 || value > ta::sweep_max_tile_planes()) return fail(TA_EINVAL, "TA_OPT_TILE_PLANES must be in [0,%d]", ta::sweep_max_tile_planes());

@@ -126,6 +126,15 @@ __device__ inline void run_add_global(const SweepArgs& A, uint32_t label, uint64
     atomicMin(box + 2, (int32_t)c);   atomicMin(box + 5, -(int32_t)c);
 }
 
+// RLE path (kernels_rle.hip): the row-run sweep keeps its run records, the adjacency is computed from them
+struct RleArgs {
+    SweepArgs a;
+    uint32_t* rle;           // [wave tiles][3][rcap]: closing label | voxel to the right | c0 | n << 9 | b << 19 | a << 23
+    uint4* dir;              // [wave tiles][tile_planes * RB] per row: first record, records, uniform label, -
+    uint32_t* hdr;           // [wave tiles] records written
+    uint32_t rcap;
+};
+
 template <typename T>
 __device__ __forceinline__ uint32_t load_label(const void* vol, int64_t idx) {
     return (uint32_t)((const T*)vol)[idx];
