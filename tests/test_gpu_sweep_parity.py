@@ -32,7 +32,7 @@ CASES = [
 ]
 
 
-@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5], ids=["naive", "default", "split", "rowrun", "fused", "rle"])
+@pytest.mark.parametrize("impl", [1, 0, 2, 3, 4, 5, 6], ids=["naive", "default", "split", "rowrun", "fused", "rle", "scan"])
 @pytest.mark.parametrize("name,make", CASES, ids=[c[0] for c in CASES])
 def test_accumulators_match_oracle(gpu_ctx, name, make, impl):
     vol = make()
@@ -41,7 +41,7 @@ def test_accumulators_match_oracle(gpu_ctx, name, make, impl):
     assert_same_accumulators(got, want, "%s impl=%d" % (name, impl))
 
 
-@pytest.mark.parametrize("impl", [0, 2, 3, 4, 5], ids=["default", "split", "rowrun", "fused", "rle"])
+@pytest.mark.parametrize("impl", [0, 2, 3, 4, 5, 6], ids=["default", "split", "rowrun", "fused", "rle", "scan"])
 @pytest.mark.parametrize("tile_planes", [1, 2, 5, 64])
 def test_tile_planes_do_not_change_results(gpu_ctx, tile_planes, impl):
     vol = voronoi((23, 40, 300), 50, 11, np.uint32)
@@ -53,7 +53,7 @@ def test_tile_planes_do_not_change_results(gpu_ctx, tile_planes, impl):
 @pytest.mark.parametrize("features", [_capi.F_VOLUME | _capi.F_BBOX | _capi.F_MOMENT1,
                                       _capi.F_VOLUME | _capi.F_BBOX | _capi.F_MOMENT1 | _capi.F_ADJACENCY,
                                       _capi.F_VOLUME | _capi.F_BBOX | _capi.F_MOMENT1 | _capi.F_MOMENT2])
-@pytest.mark.parametrize("impl", [0, 2, 3, 4, 5], ids=["default", "split", "rowrun", "fused", "rle"])
+@pytest.mark.parametrize("impl", [0, 2, 3, 4, 5, 6], ids=["default", "split", "rowrun", "fused", "rle", "scan"])
 def test_feature_subsets(gpu_ctx, features, impl):
     vol = voronoi((20, 33, 260), 40, 12, np.uint32)
     want = onepass_c.extract(vol)

@@ -1,0 +1,732 @@
+// kernels_scan.hip -- the row-run sweep with SCAN-ALLOCATED record buffers (TA_OPT_IMPL = 6).
+//
+// Same decomposition, register-resident neighbours, workgroup LDS tables and flush as the row-run
+// sweep of kernels_rowrun.hip.  What changes is how the (sparse: ~2 of 64 lanes per compare) events
+// reach the dense 64-wide consumer:
+//   * per row every lane counts its events (one v_addc per compare), ONE packed DPP add-scan over the
+//     lanes gives each lane the offset of its first record, and a firing lane then stores its record at
+//     its own running offset (store + one v_add under the compare's mask).  No per-compare ballot /
+//     mask-prefix / popcount / SGPR cursor arithmetic, no live 64-bit masks;
+//   * the per-wave buffers are LINEAR and drained completely (no ring wrap arithmetic); the drain is
+//     checked once per row, BEFORE the row is emitted, from the totals the scan produced;
+//   * records of a row land sorted by column, so a run record only carries the column where its run
+//     ENDS: the consumer takes the start from the record before it (same row) -- no max-scan for run
+//     starts in the producer, no per-compare bookkeeping.
+// Records: faces of axis 0/1 {voxel, neighbour | axis << 30}; runs {right voxel, closing label,
+// k | b << 10 | a << 14} (k = end column of the run = column of the right voxel).
+#include "ta_sweep_common.h"
+
+namespace ta {
+
+#ifndef TA_FCAP
+#define TA_FCAP 256
+#endif
+#ifndef TA_RCAP
+#define TA_RCAP 160
+#endif
+#ifndef TA_FDRAIN
+#define TA_FDRAIN 120
+#endif
+#ifndef TA_RDRAIN
+#define TA_RDRAIN 120
+#endif
+constexpr int FCAP = TA_FCAP, RCAP = TA_RCAP;           // record capacities of a wave's buffers
+constexpr int FDRAIN = TA_FDRAIN, RDRAIN = TA_RDRAIN;   // drain a buffer before a row once it holds this much
+constexpr uint32_t ROWID_MASK = 0xFFFFFC00u;            // bits of a run code that name the row (b, a, and the zero top bits)
+constexpr uint32_t NO_ROW = 0xFFFFFFFFu;                // code of the sentinel: never equal to a record's row
+
+typedef __attribute__((address_space(3))) uint32_t* lds_u32;
+
+struct __attribute__((aligned(16))) ScanWaveLds {
+    uint2 frec[FCAP];                                   // faces of axis 0/1: voxel, neighbour | axis << 30
+    uint32_t cqv[RCAP + 1], cql[RCAP + 1], cqc[RCAP + 1];   // runs; record i lives in slot i + 1, slot 0 = sentinel / carry
+};
+
+template <int NW>
+struct __attribute__((aligned(16))) ScanLds {
+    ScanWaveLds wave[WAVES];
+    uint64_t lsum[LSLOTS * NW];
+    uint64_t pkeys[PSLOTS];
+    uint32_t lbox[LSLOTS * 8];
+    uint32_t lkeys[LSLOTS];
+    uint32_t pcnt[PSLOTS * 3];
+};
+
+// inclusive add-scan over the 64 lanes: row_shr 1,2,4,8 then the two row broadcasts
+__device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
+#define TA_DPP_ADD(ctrl, rmask) \
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, false);
+    TA_DPP_ADD(0x111, 0xf) TA_DPP_ADD(0x112, 0xf) TA_DPP_ADD(0x114, 0xf) TA_DPP_ADD(0x118, 0xf)
+    TA_DPP_ADD(0x142, 0xa) TA_DPP_ADD(0x143, 0xc)
+#undef TA_DPP_ADD
+    return x;
+}
+
+// ---- workgroup tables, with the kernel arguments kept OUT of the hot loop -----------------------
+// The sweep kernels are short of SGPRs: the twenty-odd kernel arguments that only the cold paths need
+// (global rows, pair table, flags) are re-read from the kernarg segment where they are used.  The
+// pointer is laundered through an empty asm so that the loads cannot be hoisted into the hot loop.
+__device__ __forceinline__ const SweepArgs* cold_args(const SweepArgs* kp) {
+    asm volatile("" : "+s"(kp));
+    return kp;
+}
+
+__device__ __forceinline__ const SweepArgs* kernarg_args(const SweepArgs& by_value) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)by_value;        // the struct is the first (only explicit) kernel argument: it sits at offset 0 of the segment
+    return (const SweepArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#else
+    return &by_value;
+#endif
+}
+
+template <bool MOM2, typename LDS, typename SUMS>
+__device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S, uint32_t A0, uint32_t B0, uint32_t C0,
+                                               uint32_t label, const SUMS& L, uint32_t mna, uint32_t mxa, uint32_t mnb,
+                                               uint32_t mxb, uint32_t mnc, uint32_t mxc) {
+    constexpr int NW = MOM2 ? 6 : 2;
+    uint32_t h = (__umul24(label, 0x9E3779u) >> (24 - LSLOTS_LOG2)) & (LSLOTS - 1);
+    int slot = -1;
+#pragma nounroll
+    for (int probe = 0; probe < LPROBE; ++probe) {
+        uint32_t k = S.lkeys[h];
+        if (k == INVALID_LABEL) {
+            k = atomicCAS(&S.lkeys[h], INVALID_LABEL, label);
+            if (k == INVALID_LABEL) k = label;
+        }
+        if (k == label) { slot = (int)h; break; }
+        h = (h + 1) & (LSLOTS - 1);
+    }
+    if (slot >= 0) {
+        unsigned long long* row = (unsigned long long*)&S.lsum[slot * NW];
+        atomicAdd(row + 0, (unsigned long long)((uint64_t)L.n | ((uint64_t)L.sb << 32)));
+        atomicAdd(row + 1, (unsigned long long)((uint64_t)L.sa | ((uint64_t)L.sc << 32)));
+        if (MOM2) {
+            atomicAdd(row + 2, (unsigned long long)((uint64_t)L.saa | ((uint64_t)L.sab << 32)));
+            atomicAdd(row + 3, (unsigned long long)((uint64_t)L.sbb | ((uint64_t)L.sbc << 32)));
+            atomicAdd(row + (MOM2 ? 4 : 0), (unsigned long long)L.sac);
+            atomicAdd(row + (MOM2 ? 5 : 0), (unsigned long long)L.scc);
+        }
+        // bounding box: read first, touch the atomics only when this contribution extends it
+        uint32_t* box = &S.lbox[slot * 8];
+        const uint4 cur = *reinterpret_cast<const uint4*>(box);          // min a,b,c | max a
+        const uint2 cur2 = *reinterpret_cast<const uint2*>(box + 4);     // max b,c
+        if (mna < cur.x) atomicMin(box + 0, mna);
+        if (mnb < cur.y) atomicMin(box + 1, mnb);
+        if (mnc < cur.z) atomicMin(box + 2, mnc);
+        if (mxa > cur.w) atomicMax(box + 3, mxa);
+        if (mxb > cur2.x) atomicMax(box + 4, mxb);
+        if (mxc > cur2.y) atomicMax(box + 5, mxc);
+    } else {                                       // table full: straight to the global rows
+        const SweepArgs* A = cold_args(kp);
+        LocalSums Lc;
+        Lc.n = L.n; Lc.sa = L.sa; Lc.sb = L.sb; Lc.sc = L.sc; Lc.saa = L.saa; Lc.sab = L.sab;
+        Lc.sac = L.sac; Lc.sbb = L.sbb; Lc.sbc = L.sbc; Lc.scc = L.scc;
+        uint32_t bx[6];
+        bx[0] = mna; bx[1] = mnb; bx[2] = mnc; bx[3] = mxa; bx[4] = mxb; bx[5] = mxc;
+        label_spill_global(A->sums, A->boxes, A->flags, A->max_label, label, &Lc, A0, B0, C0, bx);
+    }
+}
+
+template <typename LDS>
+__device__ __forceinline__ void scan_pair_add(const SweepArgs* kp, LDS& S, uint32_t a, uint32_t b, uint32_t axis) {
+    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+    const uint64_t key = ((uint64_t)lo << 32) | hi;
+    uint32_t h = __umul24(lo, 0x9E3779u) + __umul24(hi, 0x85EBCBu);     // two full-rate 24-bit multiplies, modulo 2^24
+    h = (h >> (24 - PSLOTS_LOG2)) & (PSLOTS - 1);
+    int slot = -1;
+#pragma nounroll
+    for (int probe = 0; probe < PPROBE; ++probe) {
+        uint64_t k = S.pkeys[h];
+        if (k == EMPTY_KEY) {
+            k = atomicCAS((unsigned long long*)&S.pkeys[h], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+            if (k == EMPTY_KEY) k = key;
+        }
+        if (k == key) { slot = (int)h; break; }
+        h = (h + 1) & (PSLOTS - 1);
+    }
+    if (slot >= 0) atomicAdd(&S.pcnt[slot * 3 + axis], 1u);
+    else {
+        const SweepArgs* A = cold_args(kp);
+        pair_spill_global(A->pairs, A->flags, lo, hi, axis, 1u);
+    }
+}
+
+// one run [s, k) of a row (tile-local a, b): ten sums, every term < 2^32, every factor < 2^24
+template <bool MOM2, typename LDS>
+__device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S, uint32_t A0, uint32_t B0, uint32_t C0,
+                                                 const bool EDGE, uint32_t label, uint32_t s, uint32_t code) {
+    const uint32_t c0 = s, k = code & 1023u, bl = (code >> 10) & 15u, al = (code >> 14) & 63u;
+    const uint32_t n = k - c0;
+    if (label >= LABEL_LIMIT) {
+        // a real voxel the records cannot carry; INVALID_LABEL is the outside-the-volume filler of edge tiles only
+        if (label != INVALID_LABEL || !EDGE) atomicOr(&cold_args(kp)->flags[FLAG_RANGE], 1u);
+        return;
+    }
+    if (n == 0u) return;                  // the boundary at column 0: the run it closes belongs to the tile on the left
+    const uint32_t t1 = __umul24(n, n - 1u);                                 // n (n - 1), even
+    const uint32_t nc0 = __umul24(n, c0);
+    const uint32_t sc = nc0 + (t1 >> 1);                                     // sum c over the run
+    const uint32_t na = __umul24(n, al), nb = __umul24(n, bl);
+    RunSums L;
+    L.n = n; L.sa = na; L.sb = nb; L.sc = sc;
+    if (MOM2) {
+        L.saa = __umul24(na, al); L.sab = __umul24(na, bl); L.sbb = __umul24(nb, bl);
+        L.sac = __umul24(al, sc); L.sbc = __umul24(bl, sc);
+        L.scc = __umul24(nc0, c0) + __umul24(c0, t1) + __umul24(t1 >> 1, 2u * n - 1u) / 3u;
+    } else {
+        L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
+    }
+    scan_label_add<MOM2, LDS, RunSums>(kp, S, A0, B0, C0, label, L, al, al, bl, bl, c0, k - 1u);
+}
+
+// Drain both buffers of a wave completely, 64 records per pass, every lane busy but in the last pass.
+template <bool ADJ, bool MOM2, typename LDS>
+__device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S, uint32_t A0, uint32_t B0, uint32_t C0,
+                                              const bool EDGE, int w, int lane, uint32_t& fcount, uint32_t& rcount) {
+    auto& W = S.wave[w];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (TA_ABLATE >= 1) { fcount = 0u; rcount = 0u; return; }
+    if (ADJ) {
+        for (uint32_t i = 0; i < fcount; i += 64u) {
+            const uint32_t idx = i + (uint32_t)lane;
+            const uint2 rec = W.frec[idx < (uint32_t)FCAP ? idx : 0u];
+            if (idx < fcount) {
+                const uint32_t v = rec.x, pv = rec.y & 0x3fffffffu, axis = rec.y >> 30;
+                // records that touch the outside-the-volume filler are dropped; a label the record words cannot
+                // carry (>= LABEL_LIMIT) raises FLAG_RANGE through the run record of its own voxel
+                if (v < LABEL_LIMIT && pv < LABEL_LIMIT) scan_pair_add(kp, S, pv, v, axis);
+            }
+        }
+        fcount = 0u;
+    }
+    for (uint32_t i = 0; i < rcount; i += 64u) {
+        const uint32_t idx = i + (uint32_t)lane;
+        const uint32_t slot = idx < (uint32_t)RCAP ? idx : 0u;
+        const uint32_t prev = W.cqc[slot], code = W.cqc[slot + 1u], label = W.cql[slot + 1u];
+        const uint32_t v = ADJ ? W.cqv[slot + 1u] : 0u;
+        if (idx < rcount) {
+            if (ADJ && v < LABEL_LIMIT && label < LABEL_LIMIT) scan_pair_add(kp, S, label, v, 2u);
+            const uint32_t s = ((prev ^ code) & ROWID_MASK) == 0u ? (prev & 1023u) : 0u;
+            consume_scan_run<MOM2, LDS>(kp, S, A0, B0, C0, EDGE, label, s, code);
+        }
+    }
+    if (rcount) {
+        // carry: the record that follows (if it belongs to the same row) starts where the last one ended
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (lane == 0) W.cqc[0] = W.cqc[rcount];
+        rcount = 0u;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// strip load of this file: like load_strip, but the scalar path of edge tiles also reports a REAL voxel that
+// equals the outside-the-volume filler (0xFFFFFFFF in a uint32 volume: above any max_label)
+template <typename T, int VPL>
+__device__ __forceinline__ void scan_load_strip(const bool EDGE, const T* row_c0, bool row_ok, uint32_t lane_off,
+                                                int64_t c, int64_t n2, uint32_t (&dst)[VPL], bool& bad) {
+    if (!EDGE) {
+        const uint4 x = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(row_c0) + lane_off);
+        if (sizeof(T) == 4) {
+            dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
+        } else {
+            dst[0] = x.x & 0xffffu; dst[1] = x.x >> 16; dst[2] = x.y & 0xffffu; dst[3] = x.y >> 16;
+            dst[4 % VPL] = x.z & 0xffffu; dst[5 % VPL] = x.z >> 16;
+            dst[6 % VPL] = x.w & 0xffffu; dst[7 % VPL] = x.w >> 16;
+        }
+    } else {
+        const T* lane_p = reinterpret_cast<const T*>(reinterpret_cast<const char*>(row_c0) + lane_off);
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const bool ok = row_ok && c + j < n2;
+            dst[j] = ok ? (uint32_t)lane_p[j] : INVALID_LABEL;
+            if (sizeof(T) == 4) bad |= ok && dst[j] == INVALID_LABEL;
+        }
+    }
+}
+
+// ---- interior tiles: the plane loads are issued by hand --------------------------------------------
+// The compiler's vmcnt bookkeeping gives up at the loop's control-flow joins and waits for vmcnt(0) at the top
+// of every plane -- right after the next plane's loads were issued, so the "prefetch" never overlaps anything
+// and every wave eats a full HBM round trip per plane.  Here the loads are inline asm the compiler does not
+// count: raw 16-byte strips land in `nraw` one plane ahead and ONE s_waitcnt vmcnt(0) sits just before they are
+// unpacked into the working registers, a whole plane of compute after they were issued.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// The plane in flight lives in registers the compiler never allocates: the kernels are compiled with
+// amdgpu_num_vgpr(TA_PIN_BASE), and v[TA_PIN_BASE ..] are named explicitly here: v104..v107 + 4 r = row r of the
+// wave tile, the next quad = the row above it, then one register for lanes 0..RB-1: the voxel left of each row.
+// (Loading into ordinary asm outputs does not work: the register allocator copies a loop-carried output at the
+// back edge, i.e. reads it while the load is still in flight; accumulation registers make the compiler split the
+// unified file in halves.)
+#define TA_PIN_BASE 104
+#define TA_PIN_CLOBBERS "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", \
+                        "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124"
+template <int Q>      // quad Q of the pinned registers <- 16 bytes at sbase + voff
+__device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
+    if (Q == 0)      asm volatile("global_load_dwordx4 v[104:107], %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+    else if (Q == 1) asm volatile("global_load_dwordx4 v[108:111], %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+    else if (Q == 2) asm volatile("global_load_dwordx4 v[112:115], %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+    else if (Q == 3) asm volatile("global_load_dwordx4 v[116:119], %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+    else             asm volatile("global_load_dwordx4 v[120:123], %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+}
+template <typename T, int RB>
+__device__ __forceinline__ void issue_voxel(uint32_t voff, const void* sbase) {
+    if (sizeof(T) == 4) {
+        if (RB == 4) asm volatile("global_load_dword v124, %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+        else         asm volatile("global_load_dword v116, %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+    } else {
+        if (RB == 4) asm volatile("global_load_ushort v124, %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+        else         asm volatile("global_load_ushort v116, %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+    }
+}
+// wait for every hand-issued load and move the plane into ordinary registers
+template <int RB>
+__device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {
+    if (RB == 4) {
+        asm volatile("s_waitcnt vmcnt(0)\n"
+                     "v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n v_mov_b32 %2, v106\n v_mov_b32 %3, v107\n"
+                     "v_mov_b32 %4, v108\n v_mov_b32 %5, v109\n v_mov_b32 %6, v110\n v_mov_b32 %7, v111\n"
+                     "v_mov_b32 %8, v112\n v_mov_b32 %9, v113\n v_mov_b32 %10, v114\n v_mov_b32 %11, v115\n"
+                     "v_mov_b32 %12, v116\n v_mov_b32 %13, v117\n v_mov_b32 %14, v118\n v_mov_b32 %15, v119\n"
+                     "v_mov_b32 %16, v120\n v_mov_b32 %17, v121\n v_mov_b32 %18, v122\n v_mov_b32 %19, v123\n"
+                     "v_mov_b32 %20, v124\n"
+                     : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
+                       "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
+                       "=&v"(raw[RB > 2 ? 2 : 0].x), "=&v"(raw[RB > 2 ? 2 : 0].y), "=&v"(raw[RB > 2 ? 2 : 0].z), "=&v"(raw[RB > 2 ? 2 : 0].w),
+                       "=&v"(raw[RB > 3 ? 3 : 0].x), "=&v"(raw[RB > 3 ? 3 : 0].y), "=&v"(raw[RB > 3 ? 3 : 0].z), "=&v"(raw[RB > 3 ? 3 : 0].w),
+                       "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
+                     :: "memory");
+    } else {
+        asm volatile("s_waitcnt vmcnt(0)\n"
+                     "v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n v_mov_b32 %2, v106\n v_mov_b32 %3, v107\n"
+                     "v_mov_b32 %4, v108\n v_mov_b32 %5, v109\n v_mov_b32 %6, v110\n v_mov_b32 %7, v111\n"
+                     "v_mov_b32 %8, v112\n v_mov_b32 %9, v113\n v_mov_b32 %10, v114\n v_mov_b32 %11, v115\n"
+                     "v_mov_b32 %12, v116\n"
+                     : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
+                       "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
+                       "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
+                     :: "memory");
+    }
+}
+template <typename T, int VPL>
+__device__ __forceinline__ void unpack_strip(const u32x4& x, uint32_t (&dst)[VPL]) {
+    if (sizeof(T) == 4) {
+        dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
+    } else {
+        dst[0] = x.x & 0xffffu; dst[1] = x.x >> 16; dst[2] = x.y & 0xffffu; dst[3] = x.y >> 16;
+        dst[4 % VPL] = x.z & 0xffffu; dst[5 % VPL] = x.z >> 16;
+        dst[6 % VPL] = x.w & 0xffffu; dst[7 % VPL] = x.w >> 16;
+    }
+}
+
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, typename LDS>
+__device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* kp, LDS& S, const int lane, const int w,
+                                          const uint32_t c_tile0, const uint32_t b_tile0,
+                                          const int32_t p_lo, const int32_t p_hi, const uint32_t A0) {
+    constexpr int TC = 64 * VPL;
+    static_assert(TC <= 512, "the run code holds the end column in 10 bits");
+    static_assert(FCAP >= 2 * VPL && RCAP >= VPL + 1, "the records of one lane must fit a buffer");
+    auto& W = S.wave[w];
+
+    const T* vol = reinterpret_cast<const T*>(A.vol);
+    const int64_t n1 = A.n1, n2 = A.n2, plane = n1 * n2;
+    const int64_t b_wave0 = (int64_t)b_tile0 + (int64_t)w * RB;
+    const int64_t c0g = (int64_t)c_tile0 + (int64_t)lane * VPL;
+    const bool has_up = ADJ && b_wave0 > 0;
+    const bool has_left = ADJ && c_tile0 > 0;
+    const bool has_prev = ADJ && p_lo > 0;
+    const uint32_t lane_c = (uint32_t)lane * VPL;
+    const uint32_t lane_off = lane_c * (uint32_t)sizeof(T);
+
+    uint32_t cur[RB][VPL], prv[RB][VPL], up[VPL];
+    uint32_t leftv = INVALID_LABEL;                        // lane r: the voxel left of row r of the tile
+    // the plane in flight: unpacked (edge tiles, compiler-managed loads) or raw strips (interior tiles, hand-issued)
+    uint32_t nxt[RB][VPL], nxt_up[VPL], nxt_leftv = INVALID_LABEL;
+    u32x4 nraw[RB], nup_raw;                               // (the plane just read back from the pinned registers)
+    static_assert(RB == 2 || RB == 4, "the pinned-register layout is written out for 2 and 4 rows");
+    bool bad = false;
+
+    // -- edge tiles: plain loads with bounds, the compiler waits as it sees fit
+    auto load_rows = [&](int64_t p, uint32_t (&d)[RB][VPL]) {
+        const T* pbase = vol + p * plane;
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const int64_t b = b_wave0 + r;
+            const bool row_ok = b < n1;
+            const T* row = pbase + (row_ok ? b : 0) * n2 + c_tile0;
+            scan_load_strip<T, VPL>(true, row, row_ok, lane_off, c0g, n2, d[r], bad);
+        }
+    };
+    auto load_halo = [&](int64_t p, uint32_t (&dup)[VPL], uint32_t& dl) {
+        const T* pbase = vol + p * plane;
+        if (has_left) {
+            const int64_t b = b_wave0 + lane;
+            dl = (lane < RB && b < n1) ? (uint32_t)pbase[b * n2 + c_tile0 - 1] : INVALID_LABEL;
+        }
+        if (has_up) {
+            const bool row_ok = (b_wave0 - 1) < n1;
+            const T* row = pbase + (row_ok ? (b_wave0 - 1) : 0) * n2 + c_tile0;
+            scan_load_strip<T, VPL>(true, row, row_ok, lane_off, c0g, n2, dup, bad);
+        }
+    };
+    // -- interior tiles: every load is unconditional (a tile without a row above / a column to the left reads its
+    //    own first row / column instead and never looks at the result), RB + 2 loads per plane
+    const uint32_t rowbytes = (uint32_t)(n2 * (int64_t)sizeof(T));
+    const uint32_t left_off = (uint32_t)(lane & (RB - 1)) * rowbytes;    // (the VGPR offset of a load is unsigned)
+    auto issue_plane = [&](int64_t p) {
+        const char* row0 = reinterpret_cast<const char*>(vol + p * plane + b_wave0 * n2 + c_tile0);
+        issue_strip<0>(lane_off, row0);
+        issue_strip<1>(lane_off, row0 + rowbytes);
+        if (RB > 2) { issue_strip<2>(lane_off, row0 + 2 * (int64_t)rowbytes); issue_strip<3>(lane_off, row0 + 3 * (int64_t)rowbytes); }
+        if (RB > 2) issue_strip<4>(lane_off, has_up ? row0 - rowbytes : row0);
+        else        issue_strip<2>(lane_off, has_up ? row0 - rowbytes : row0);
+        issue_voxel<T, RB>(left_off, has_left ? row0 - sizeof(T) : row0);
+    };
+
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) { up[j] = INVALID_LABEL; nxt_up[j] = INVALID_LABEL; }
+    if constexpr (EDGE) {
+        load_rows(p_lo, cur);
+        load_halo(p_lo, up, leftv);
+        if (has_prev) {
+            load_rows(p_lo - 1, prv);      // the plane before the tile (another tile's, or the slab's halo plane)
+        } else {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) prv[r][j] = cur[r][j];
+        }
+        if (p_lo + 1 < p_hi) { load_rows(p_lo + 1, nxt); load_halo(p_lo + 1, nxt_up, nxt_leftv); }
+    } else {
+        if (has_prev) {
+            issue_plane(p_lo - 1);
+            landed<RB>(nraw, nup_raw, nxt_leftv);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], prv[r]);
+        }
+        issue_plane(p_lo);
+        landed<RB>(nraw, nup_raw, nxt_leftv);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], cur[r]);
+        unpack_strip<T, VPL>(nup_raw, up);
+        leftv = nxt_leftv;
+        if (!has_prev) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) prv[r][j] = cur[r][j];
+        }
+        if (p_lo + 1 < p_hi) issue_plane(p_lo + 1);
+    }
+
+    uint32_t fcount = 0u, rcount = 0u;                    // records in the buffers (wave-uniform)
+    if (lane == 0) W.cqc[0] = NO_ROW;
+    // Leading rows of the tile that are one label (the label of its first voxel) from end to end are not records:
+    // they are counted and added in closed form at the end -- that is the whole cost of background.
+    const uint32_t first_label = __builtin_amdgcn_readfirstlane(cur[0][0]);
+    bool leading = true;
+    uint32_t nlead = 0u;
+    // LDS byte offsets of the wave's buffers (the low half of a flat LDS address is the LDS offset)
+    const uint32_t fbase = (uint32_t)(uintptr_t)&W.frec[0];
+    const uint32_t rbase = (uint32_t)(uintptr_t)&W.cqv[1];
+    constexpr uint32_t RSTRIDE = (RCAP + 1) * 4u;         // bytes between the three run arrays
+    const uint32_t B0 = b_tile0, C0 = c_tile0;
+
+#ifdef TA_STAMPS
+    uint64_t tk_cmp = 0, tk_emit = 0, tk_drain = 0, tk_adv = 0, tk_rows = 0, tk_evrows = 0, tk_drains = 0;
+    const uint64_t tk_begin = __builtin_amdgcn_s_memtime();
+#define TA_T() __builtin_amdgcn_s_memtime()
+#endif
+    for (int32_t p = p_lo; p < p_hi; ++p) {
+        const uint32_t ploc = (uint32_t)(p - p_lo);
+#pragma unroll
+        for (int r = 0; r < RB; ++r) {
+            const uint32_t bloc = (uint32_t)(w * RB + r);
+#ifdef TA_STAMPS
+            const uint64_t t0 = TA_T();
+#endif
+            // ---- 1. compares + per-lane event counts
+            uint32_t pcv[VPL];
+            uint32_t cf = 0u, cr = 0u;
+            uint64_t inner = 0ull;                        // boundaries inside the row (the halo compare of lane 0 left out)
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const uint32_t v = cur[r][j];
+                if (j > 0) pcv[j] = cur[r][j > 0 ? j - 1 : 0];
+                else pcv[j] = lane_shr1(cur[r][VPL - 1], has_left ? (uint32_t)__builtin_amdgcn_readlane((int)leftv, r) : cur[r][0]);
+                const bool fc = v != pcv[j];
+                cr += fc ? 1u : 0u;
+                const uint64_t mc = __builtin_amdgcn_ballot_w64(fc);
+                inner |= j == 0 ? (mc & ~1ull) : mc;
+                if (ADJ) {
+                    if (r > 0 || has_up) cf += (v != (r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j])) ? 1u : 0u;
+                    cf += (v != prv[r][j]) ? 1u : 0u;
+                }
+            }
+            const uint32_t rowlab = __builtin_amdgcn_readfirstlane(cur[r][0]);
+            const bool uniform = inner == 0ull;
+            bool need_end;                                // the row's last run closes by a record of lane 63
+            if (leading && uniform && rowlab == first_label) { nlead += 1u; need_end = false; }
+            else { leading = false; need_end = !(uniform && rowlab == INVALID_LABEL); }
+            if (!EDGE && uniform && rowlab == INVALID_LABEL) bad = true;      // not a filler: a voxel above any max_label
+            if (need_end && lane == 63) cr += 1u;
+            const uint32_t cnt = cf | (cr << 16);         // faces in the low half, runs in the high half
+#ifdef TA_STAMPS
+            const bool anyev_ = __builtin_amdgcn_ballot_w64(cnt != 0u) != 0ull;
+            const uint64_t t1 = TA_T();
+            tk_cmp += t1 - t0; tk_rows += 1;
+            if (!anyev_) continue;
+            tk_evrows += 1;
+#else
+            if (__builtin_amdgcn_ballot_w64(cnt != 0u) == 0ull) continue;       // the common case: one branch per row
+#endif
+
+            // ---- 2. one packed add-scan over the lanes gives every lane the offset of its first record; the totals
+            //         say whether the row fits.  One trip, unless the row does not fit: then the buffers are drained
+            //         first, and a row too big even for empty buffers (noise, never tissue) goes a lane range at a time.
+            uint32_t lo = 0u, hi = 64u;
+            for (;;) {
+                // (laundered: keeps the tagged / coded copies of the row's registers from being hoisted out of this
+                //  loop into long-lived registers)
+                uint32_t tag1 = 1u << 30;
+                uint32_t rowcode = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bloc << 10) | (ploc << 14)));
+                if (ADJ) asm volatile("" : "+s"(tag1));
+                asm volatile("" : "+s"(rowcode));
+                const bool insel = ((uint32_t)lane - lo) < (hi - lo);
+                const uint32_t mine = insel ? cnt : 0u;
+                const uint32_t incl = wave_scan_add(mine);
+                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+                const uint32_t rowf = tot & 0xffffu, rowr = tot >> 16;
+                const bool fits = fcount + rowf <= (uint32_t)FCAP && rcount + rowr <= (uint32_t)RCAP;
+                if (TA_ABLATE >= 3) break;
+                if (fits) {
+                    const uint32_t excl = incl - mine;
+                    uint32_t offf = fbase + ((fcount + (excl & 0xffffu)) << 3);     // LDS address of the lane's next face record
+                    uint32_t offr = rbase + ((rcount + (excl >> 16)) << 2);         // ... and of its next run record (first array)
+                    fcount += rowf; rcount += rowr;
+                    if (insel && TA_ABLATE < 2) {
+                        // ---- 3. emit: a firing lane stores at its own offset and steps it
+#pragma unroll
+                        for (int j = 0; j < VPL; ++j) {
+                            const uint32_t v = cur[r][j];
+                            if (ADJ) {
+                                if (r > 0 || has_up) {
+                                    const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];
+                                    if (v != pv) {
+                                        *(lds_u32)(uintptr_t)offf = v; *(lds_u32)(uintptr_t)(offf + 4u) = pv | tag1;
+                                        offf += 8u;
+                                    }
+                                }
+                                {
+                                    const uint32_t pv = prv[r][j];
+                                    if (v != pv) {
+                                        *(lds_u32)(uintptr_t)offf = v; *(lds_u32)(uintptr_t)(offf + 4u) = pv;
+                                        offf += 8u;
+                                    }
+                                }
+                            }
+                            if (v != pcv[j]) {
+                                if (ADJ) *(lds_u32)(uintptr_t)offr = v;
+                                *(lds_u32)(uintptr_t)(offr + RSTRIDE) = pcv[j];
+                                *(lds_u32)(uintptr_t)(offr + 2u * RSTRIDE) = (lane_c + (uint32_t)j) | rowcode;
+                                offr += 4u;
+                            }
+                        }
+                        if (need_end && lane == 63) {
+                            if (ADJ) *(lds_u32)(uintptr_t)offr = INVALID_LABEL;
+                            *(lds_u32)(uintptr_t)(offr + RSTRIDE) = cur[r][VPL - 1];
+                            *(lds_u32)(uintptr_t)(offr + 2u * RSTRIDE) = (uint32_t)TC | rowcode;
+                        }
+                    }
+                    lo = hi; hi = 64u;
+                } else if ((fcount | rcount) == 0u) {
+                    hi = lo + ((hi - lo) >> 1);           // too big even for empty buffers: half the lanes
+                    continue;
+                }
+#ifdef TA_STAMPS
+                const uint64_t t2 = TA_T();
+                tk_emit += t2 - t1;
+#endif
+                if (!fits || fcount >= (uint32_t)FDRAIN || rcount >= (uint32_t)RDRAIN) {
+                    drain_buffers<ADJ, MOM2, LDS>(kp, S, A0, B0, C0, EDGE, w, lane, fcount, rcount);
+#ifdef TA_STAMPS
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    tk_drain += TA_T() - t2; tk_drains += 1;
+#endif
+                }
+                if (lo >= 64u) break;
+            }
+        }
+        // ---- advance: the plane in flight becomes the current one, the next one is issued
+#ifdef TA_STAMPS
+        const uint64_t t4 = TA_T();
+#endif
+        if (p + 1 < p_hi) {
+            if constexpr (EDGE) {
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) {
+                        if (ADJ) prv[r][j] = cur[r][j];
+                        cur[r][j] = nxt[r][j];
+                    }
+                }
+                leftv = nxt_leftv;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) up[j] = nxt_up[j];
+                if (p + 2 < p_hi) { load_rows(p + 2, nxt); load_halo(p + 2, nxt_up, nxt_leftv); }
+            } else {
+                landed<RB>(nraw, nup_raw, nxt_leftv);                    // issued a whole plane of compute ago
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    if (ADJ) {
+#pragma unroll
+                        for (int j = 0; j < VPL; ++j) prv[r][j] = cur[r][j];
+                    }
+                    unpack_strip<T, VPL>(nraw[r], cur[r]);
+                }
+                if (ADJ) unpack_strip<T, VPL>(nup_raw, up);
+                leftv = nxt_leftv;
+                if (p + 2 < p_hi) issue_plane(p + 2);
+            }
+        }
+#ifdef TA_STAMPS
+        tk_adv += TA_T() - t4;
+#endif
+    }
+#ifdef TA_STAMPS
+    if (lane == 0) {
+        uint32_t* fl = cold_args(kp)->flags;
+        atomicAdd(&fl[8], (uint32_t)(tk_cmp >> 8)); atomicAdd(&fl[9], (uint32_t)(tk_emit >> 8));
+        atomicAdd(&fl[10], (uint32_t)(tk_drain >> 8)); atomicAdd(&fl[11], (uint32_t)(tk_adv >> 8));
+        atomicAdd(&fl[12], (uint32_t)((TA_T() - tk_begin) >> 8));
+        atomicAdd(&fl[13], (uint32_t)tk_rows); atomicAdd(&fl[14], (uint32_t)tk_evrows); atomicAdd(&fl[15], (uint32_t)tk_drains);
+    }
+#endif
+
+    // ---- end of tile: drain the buffers, then the leading one-label rows in one closed form
+    drain_buffers<ADJ, MOM2, LDS>(kp, S, A0, B0, C0, EDGE, w, lane, fcount, rcount);
+    if (__builtin_amdgcn_ballot_w64(bad)) { if (lane == 0) atomicOr(&cold_args(kp)->flags[FLAG_RANGE], 1u); }
+    if (lane == 0 && nlead != 0u && first_label != INVALID_LABEL) {
+        // rows in (plane, row) order: P full planes of RB rows, then R rows of plane P
+        const uint64_t P = nlead / RB, R = nlead % RB, nc = TC, b0 = (uint64_t)w * RB;
+        const uint64_t t1c = range_sum1(0, nc), t2c = range_sum2(0, nc);
+        const uint64_t rows = P * RB + R;                                        // = nlead
+        const uint64_t sa_rows = range_sum1(0, P) * RB + P * R;                  // sum of a over the rows
+        const uint64_t saa_rows = range_sum2(0, P) * RB + P * P * R;
+        const uint64_t sb_rows = P * range_sum1(b0, RB) + range_sum1(b0, R);
+        const uint64_t sbb_rows = P * range_sum2(b0, RB) + range_sum2(b0, R);
+        const uint64_t sab_rows = range_sum1(0, P) * range_sum1(b0, RB) + P * range_sum1(b0, R);
+        LocalSums L;
+        L.n = rows * nc; L.sa = sa_rows * nc; L.sb = sb_rows * nc; L.sc = rows * t1c;
+        if (MOM2) {
+            L.saa = saa_rows * nc; L.sab = sab_rows * nc; L.sbb = sbb_rows * nc;
+            L.sac = sa_rows * t1c; L.sbc = sb_rows * t1c; L.scc = rows * t2c;
+        } else {
+            L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
+        }
+        const uint32_t mxa = (uint32_t)(R ? P : P - 1u);
+        const uint32_t mxb = (uint32_t)(b0 + (P ? RB : R) - 1u);
+        scan_label_add<MOM2, LDS, LocalSums>(kp, S, A0, B0, C0, first_label, L, 0u, mxa, (uint32_t)b0, mxb, 0u,
+                                             (uint32_t)(nc - 1));
+    }
+}
+
+// Tiles of a volume: `fc` x `fb` full tiles per plane band go to the interior kernel (hand-issued 16-byte loads, no
+// bounds), the partial tiles of the last tile column / tile row (or everything, when the rows are not 16-byte
+// aligned) to the edge kernel.  Both write the same tables; `wg0` numbers the edge kernel's workgroups after
+// the interior kernel's (private hot-label rows).
+struct ScanSplit { uint32_t tiles_c, tiles_b, fc, fb, nbands; };
+
+template <int VPL, int RB>
+static ScanSplit scan_split(const SweepArgs& a, int itemsize) {
+    constexpr int TC = 64 * VPL, TB = WAVES * RB;
+    ScanSplit s;
+    const int64_t owned = a.n0 - a.first_owned;
+    s.tiles_c = (uint32_t)((a.n2 + TC - 1) / TC); s.tiles_b = (uint32_t)((a.n1 + TB - 1) / TB);
+    s.nbands = owned <= 0 ? 0u : (uint32_t)((owned + a.tile_planes - 1) / a.tile_planes);
+    const bool fast = a.vec_ok && a.n2 * itemsize * (int64_t)RB < (1ll << 31);
+    s.fc = fast ? (uint32_t)(a.n2 / TC) : 0u; s.fb = fast ? (uint32_t)(a.n1 / TB) : 0u;
+    if (s.fc == 0 || s.fb == 0) { s.fc = 0; s.fb = 0; }
+    return s;
+}
+
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE>
+__global__ void __launch_bounds__(WAVES * 64, TA_MINWAVES) __attribute__((amdgpu_num_vgpr(TA_PIN_BASE))) scan_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+    constexpr int NW = MOM2 ? 6 : 2;
+    constexpr int TC = 64 * VPL, TB = WAVES * RB;
+    static_assert(TB <= 16 && TC <= 512, "packed LDS moment words assume <= 16 rows x 512 columns per tile");
+    using LDS = ScanLds<NW>;
+    __shared__ LDS S;
+    // the arguments only the cold paths need are re-read from the kernarg segment there (see cold_args)
+    const SweepArgs* kp = kernarg_args(A);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < LSLOTS; i += WAVES * 64) {
+        S.lkeys[i] = INVALID_LABEL;
+#pragma unroll
+        for (int k = 0; k < NW; ++k) S.lsum[i * NW + k] = 0ull;
+        S.lbox[i * 8 + 0] = 0xFFFFFFFFu; S.lbox[i * 8 + 1] = 0xFFFFFFFFu; S.lbox[i * 8 + 2] = 0xFFFFFFFFu;
+        S.lbox[i * 8 + 3] = 0u; S.lbox[i * 8 + 4] = 0u; S.lbox[i * 8 + 5] = 0u;
+    }
+    if (ADJ) {
+        for (int i = tid; i < PSLOTS; i += WAVES * 64) {
+            S.pkeys[i] = EMPTY_KEY;
+            S.pcnt[i * 3 + 0] = 0u; S.pcnt[i * 3 + 1] = 0u; S.pcnt[i * 3 + 2] = 0u;
+        }
+    }
+    const uint32_t wg = wg0 + blockIdx.x;
+    if (!ADJ) hot_row_init(A, tid, wg);
+    __syncthreads();
+
+    uint32_t t = blockIdx.x, tc, tb, band;
+    if (!EDGE) {
+        tc = t % sp.fc; t /= sp.fc; tb = t % sp.fb; band = t / sp.fb;
+    } else {
+        const uint32_t per_band = sp.tiles_c * sp.tiles_b - sp.fc * sp.fb, strip = (sp.tiles_c - sp.fc) * sp.tiles_b;
+        band = t / per_band; t -= band * per_band;
+        if (t < strip) { tc = sp.fc + t % (sp.tiles_c - sp.fc); tb = t / (sp.tiles_c - sp.fc); }       // the last tile column(s)
+        else { t -= strip; tc = t % sp.fc; tb = sp.fb + t / sp.fc; }                                    // the last tile row(s)
+    }
+    const uint32_t c_tile0 = tc * TC, b_tile0 = tb * TB;
+    const int32_t p_lo = A.first_owned + (int32_t)band * A.tile_planes;
+    int32_t p_hi = p_lo + A.tile_planes;
+    if (p_hi > (int32_t)A.n0) p_hi = (int32_t)A.n0;
+    const uint64_t A0 = (uint64_t)(A.a_origin + (p_lo - A.first_owned));
+
+    if (p_lo < p_hi)
+        wave_scan<T, VPL, RB, ADJ, MOM2, EDGE>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi, (uint32_t)A0);
+    __syncthreads();
+    const SweepArgs& Ac = *cold_args(kp);
+    flush_tables<NW, ADJ, MOM2, !ADJ>(Ac, S, tid, A0, (uint64_t)b_tile0, (uint64_t)c_tile0,
+                                      ADJ ? 0u : hot_label_of<T>(Ac), wg);
+}
+
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2>
+static void launch_scan_tt(hipStream_t s, const SweepArgs& a) {
+    const ScanSplit sp = scan_split<VPL, RB>(a, (int)sizeof(T));
+    if (sp.nbands == 0 || a.n1 <= 0 || a.n2 <= 0) return;
+    const uint32_t n_in = sp.fc * sp.fb * sp.nbands;
+    const uint32_t n_ed = (sp.tiles_c * sp.tiles_b - sp.fc * sp.fb) * sp.nbands;
+    const dim3 block(WAVES * 64);
+    if (n_in) hipLaunchKernelGGL((scan_kernel<T, VPL, RB, ADJ, MOM2, false>), dim3(n_in), block, 0, s, a, sp, 0u);
+    if (n_ed) hipLaunchKernelGGL((scan_kernel<T, VPL, RB, ADJ, MOM2, true>), dim3(n_ed), block, 0, s, a, sp, n_in);
+}
+
+template <typename T, int VPL, int RB>
+static void launch_scan_t(hipStream_t s, const SweepArgs& a, uint32_t fm) {
+    const bool adj = fm & 16u, mom2 = fm & 8u;
+    if (adj && mom2)       launch_scan_tt<T, VPL, RB, true, true>(s, a);
+    else if (adj && !mom2) launch_scan_tt<T, VPL, RB, true, false>(s, a);
+    else if (!adj && mom2) launch_scan_tt<T, VPL, RB, false, true>(s, a);
+    else                   launch_scan_tt<T, VPL, RB, false, false>(s, a);
+}
+
+void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask) {
+    if (itemsize == 2) launch_scan_t<uint16_t, 8, 2>(s, a, feature_mask);
+    else               launch_scan_t<uint32_t, 4, TA_RB32>(s, a, feature_mask);
+}
+
+}  // namespace ta

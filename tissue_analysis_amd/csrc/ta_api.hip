@@ -163,7 +163,7 @@ int run_extract(ta_ctx* c) {
     a.flags = flags_dev(c);
     uint64_t* hot_rows = nullptr;
     uint64_t nwg = 0;
-    const bool rowrun = c->impl == 3 || (c->impl == 0 && !(c->feature_mask & TA_F_ADJACENCY));
+    const bool rowrun = c->impl == 3 || c->impl == 6 || (c->impl == 0 && !(c->feature_mask & TA_F_ADJACENCY));
     const bool rle = c->impl == 5 && !c->split_failed && c->first_owned == 0;
     if ((rowrun && !(c->feature_mask & TA_F_ADJACENCY)) || rle) {     // the kernels that use the private hot-label rows
         nwg = ta::sweep_grid_size(a, c->itemsize);
@@ -204,6 +204,8 @@ int run_extract(ta_ctx* c) {
         if ((rc = c->rle_hdr.reserve(wave_tiles * 4 + 16)) != TA_OK) return rc;
         ra.rle = (uint32_t*)c->rle_rec.p; ra.dir = (uint4*)c->rle_dir.p; ra.hdr = (uint32_t*)c->rle_hdr.p;
         ta::launch_rle(c->stream, ra, c->itemsize, c->feature_mask);
+    } else if (c->impl == 6) {
+        ta::launch_scan(c->stream, a, c->itemsize, c->feature_mask);
     } else if (c->impl == 3 || (c->impl == 0 && !adj)) {
         // default: runs along the contiguous axis when no adjacency is asked for (moments-only sets run
         // at 55-60 % of the HBM peak there), the fused axis-0 sweep when it is (equal on C4, faster on C3)
@@ -344,7 +346,7 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
     if (!c) return fail(TA_EINVAL, "ctx is NULL");
     switch (key) {
         case TA_OPT_IMPL:
-            if (value < 0 || value > 5) return fail(TA_EINVAL, "TA_OPT_IMPL must be in [0,5]");
+            if (value < 0 || value > 6) return fail(TA_EINVAL, "TA_OPT_IMPL must be in [0,6]");
             c->impl = (int)value; return TA_OK;
         case TA_OPT_TILE_PLANES:
             if (value < 0 || value > ta::sweep_max_tile_planes()) return fail(TA_EINVAL, "TA_OPT_TILE_PLANES must be in [0,%d]", ta::sweep_max_tile_planes());

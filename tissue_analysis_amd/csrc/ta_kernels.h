@@ -37,6 +37,7 @@ void launch_sweep(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feat
 void split_region_shape(const SweepArgs& a, int itemsize, uint64_t* wave_tiles, uint32_t* fcap, uint32_t* rcap);
 void launch_split(hipStream_t s, const SplitArgs& a, int itemsize, uint32_t feature_mask);
 void launch_rowrun(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);   // kernels_rowrun.hip
+void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);     // kernels_scan.hip
 // kernels_rle.hip
 void rle_region_shape(const SweepArgs& a, int itemsize, uint64_t* wave_tiles, uint32_t* rcap, uint32_t* dir_rows);
 void launch_rle(hipStream_t s, const RleArgs& p, int itemsize, uint32_t feature_mask);

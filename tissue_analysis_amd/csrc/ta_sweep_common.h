@@ -220,19 +220,21 @@ __device__ __forceinline__ uint64_t* hot_rows_of(const SweepArgs& A) {
     typedef uint64_t* const __attribute__((address_space(4)))* cpp;          // scalar (SMEM) load of the parked pointer
     return *reinterpret_cast<cpp>(reinterpret_cast<uintptr_t>(A.flags + HOT_PTR_WORD));
 }
-__device__ __forceinline__ void hot_row_init(const SweepArgs& A, const int tid) {
+__device__ __forceinline__ void hot_row_init(const SweepArgs& A, const int tid, const uint32_t wg) {
     uint64_t* rows = hot_rows_of(A);
     if (rows && tid < HOTW) {
         const uint64_t imax2 = ((uint64_t)(uint32_t)INT32_MAX << 32) | (uint32_t)INT32_MAX;
-        rows[(uint64_t)blockIdx.x * HOTW + tid] = tid < NSUM ? 0ull : imax2;
+        rows[(uint64_t)wg * HOTW + tid] = tid < NSUM ? 0ull : imax2;
     }
 }
+__device__ __forceinline__ void hot_row_init(const SweepArgs& A, const int tid) { hot_row_init(A, tid, blockIdx.x); }
 
 // HOT = false compiles the hot-row path out (the fused adjacency kernels sit on the edge of their register
 // budget: any extra code, even here in the epilogue, tips their allocation from 1 into ~100 spilled registers).
 template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS>
 __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const int tid, const uint64_t A0,
-                                             const uint64_t B0, const uint64_t C0, const uint32_t hot) {
+                                             const uint64_t B0, const uint64_t C0, const uint32_t hot,
+                                             const uint32_t wg) {
     uint64_t* const hot_rows = HOT ? hot_rows_of(A) : nullptr;
     for (int i = tid; i < LSLOTS; i += WAVES * 64) {
         const uint32_t label = S.lkeys[i];
@@ -253,7 +255,7 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
         local_to_global(L, A0, B0, C0, g);
         // the hot label goes to this workgroup's private row: same atomics, nobody to contend with
         const bool priv = HOT && hot_rows && label == hot;
-        uint64_t* hr = hot_rows + (uint64_t)blockIdx.x * HOTW;
+        uint64_t* hr = hot_rows + (uint64_t)wg * HOTW;
         unsigned long long* row = (unsigned long long*)(priv ? hr : &A.sums[(uint64_t)label * NSUM]);
 #pragma unroll
         for (int k = 0; k < (MOM2 ? NSUM : 4); ++k) atomicAdd(row + k, (unsigned long long)g[k]);
@@ -270,6 +272,12 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
                             S.pcnt[i * 3 + 1], S.pcnt[i * 3 + 2], A.flags);
         }
     }
+}
+
+template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS>
+__device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const int tid, const uint64_t A0,
+                                             const uint64_t B0, const uint64_t C0, const uint32_t hot) {
+    flush_tables<NW, ADJ, MOM2, HOT, LDS>(A, S, tid, A0, B0, C0, hot, blockIdx.x);
 }
 
 // ---- shared by the row-run kernels (kernels_rowrun.hip, kernels_rle.hip) -----------------------
