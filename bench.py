@@ -204,7 +204,7 @@ def main():
                        "pct_hbm_roofline": round(100.0 * achieved / HBM_PEAK_GBS, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "sweep_kernel" if feats & _capi.F_ADJACENCY else "rowrun_kernel",
+                         "kernel": "scan_kernel",
                          "kernel_ms": round(sweep, 4),
                          "adjacency_collect_ms": round(float(np.mean(adj_ms)), 4),
                          "algorithmic_bytes_per_launch": int(bytes_read)},

@@ -57,12 +57,9 @@ extern "C" {
 #define TA_F_ALL       31u
 
 /* ta_ctx_set_option keys */
-#define TA_OPT_IMPL        1  /* 0 = default: the row-run sweep when no adjacency is requested, the fused
-                                 sweep when it is; 1 = per-voxel atomics (slow, for cross-checks); 2 = split
-                                 emit / reduce kernels (diagnostic; falls back to the fused sweep by itself
-                                 on volumes with more events than a region holds); 3 = row-run sweep (runs
-                                 along the contiguous axis) always; 4 = fused sweep (runs along axis 0) always;
-                                 5 = experimental: row-run sweep that keeps its runs + adjacency from the runs */
+#define TA_OPT_IMPL        1  /* 0 = default: the sweep kernel (runs along the contiguous axis, scan-allocated record
+                                 buffers, hand-issued plane loads); 1 = per-voxel global atomics (slow; shares no logic
+                                 with the sweep: the two cross-check each other on the GPU) */
 #define TA_OPT_TILE_PLANES 2  /* planes of memory axis 0 walked by one workgroup (tuning)          */
 #define TA_OPT_PAIR_SLOTS  3  /* log2 of the device adjacency hash capacity (0 = automatic)       */
 

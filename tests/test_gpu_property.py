@@ -31,7 +31,7 @@ def volumes(draw):
     v = np.ascontiguousarray(v[:shape[0], :shape[1], :shape[2]])
     order = draw(st.sampled_from(["C", "F"]))
     tile_planes = draw(st.sampled_from([1, 2, 5, 32]))
-    impl = draw(st.sampled_from([0, 2, 3, 4, 5]))
+    impl = draw(st.sampled_from([0, 0, 0, 1]))
     return (np.asfortranarray(v) if order == "F" else v), tile_planes, impl
 
 

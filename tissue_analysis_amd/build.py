@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libtissue_scan.so")
-SOURCES = ["ta_api.hip", "kernels_basic.hip", "kernels_sweep.hip", "kernels_rowrun.hip", "kernels_rle.hip", "kernels_scan.hip"]
+SOURCES = ["ta_api.hip", "kernels_basic.hip", "kernels_scan.hip"]
 HEADERS = ["ta_device.h", "ta_kernels.h", "ta_sweep_common.h", os.path.join("..", "..", "include", "tissue_scan.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-DTA_BUILD"]
@@ -32,6 +32,42 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def _check_pinned(hipcc, verbose=False):
+    """kernels_scan.hip keeps the plane in flight in VGPRs it names itself, above an amdgpu_num_vgpr budget the
+    compiler treats as a request, not a limit: refuse a build in which compiler-allocated code reaches them."""
+    asm = os.path.join(OBJDIR, "kernels_scan.check.s")
+    cmd = [hipcc] + FLAGS + ["--cuda-device-only", "-S", os.path.join(CSRC, "kernels_scan.hip"), "-o", asm]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd, cwd=OBJDIR)
+    import re
+    base = 104
+    for line in open(os.path.join(CSRC, "kernels_scan.hip")):
+        m = re.match(r"#define TA_PIN_BASE (\d+)", line)
+        if m:
+            base = int(m.group(1))
+    reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
+    in_asm, func, bad = False, None, []
+    for ln, line in enumerate(open(asm), 1):
+        t = line.strip()
+        if t.startswith(";;#ASMSTART"):
+            in_asm = True
+        elif t.startswith(";;#ASMEND"):
+            in_asm = False
+        else:
+            m = re.match(r"^(_Z\w+):", line)
+            if m:
+                func = m.group(1)
+            elif not in_asm and t and t[0] not in ";." and not (func and re.search(r"scan_kernelI\w*Lb1EEEvNS_9SweepArgs", func)):
+                for m in reg.finditer(t.split(";")[0]):
+                    if int(m.group(1) or m.group(3)) >= base:
+                        bad.append("%s:%d: %s" % (func, ln, t))
+                        break
+    if bad:
+        raise RuntimeError("compiler-allocated VGPRs reach the hand-pinned registers (>= v%d) in kernels_scan.hip:\n  %s"
+                           % (base, "\n  ".join(bad[:10])))
 
 
 def build(force=False, save_temps=False, verbose=False):
@@ -62,6 +98,8 @@ def build(force=False, save_temps=False, verbose=False):
             print(out)
     if failed:
         raise RuntimeError("hipcc compilation failed")
+    if procs and any(src == "kernels_scan.hip" for src, _ in procs):
+        _check_pinned(hipcc, verbose)
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:

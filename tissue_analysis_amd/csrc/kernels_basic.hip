@@ -206,8 +206,7 @@ __global__ void __launch_bounds__(256) pairs_pack_kernel(const uint64_t* keys, c
     uint64_t* bf = block + XHDR + cap;
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         block[0] = n;
-        block[1] = (flags[FLAG_RANGE] ? XSTATUS_RANGE : 0) | (flags[FLAG_PAIR_OVERFLOW] ? XSTATUS_PAIR_OVERFLOW : 0) |
-                   (flags[FLAG_REGION_OVERFLOW] ? XSTATUS_REGION_OVERFLOW : 0);
+        block[1] = (flags[FLAG_RANGE] ? XSTATUS_RANGE : 0) | (flags[FLAG_PAIR_OVERFLOW] ? XSTATUS_PAIR_OVERFLOW : 0);
     }
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap;
          i += (uint64_t)gridDim.x * blockDim.x) {
@@ -240,7 +239,6 @@ __global__ void __launch_bounds__(256) pairs_insert_blocks_kernel(PairTable pt, 
             const uint64_t st = blk[1];
             if (st & XSTATUS_RANGE) atomicOr(&flags[FLAG_RANGE], 1u);
             if (st & XSTATUS_PAIR_OVERFLOW) atomicOr(&flags[FLAG_PAIR_OVERFLOW], 1u);
-            if (st & XSTATUS_REGION_OVERFLOW) atomicOr(&flags[FLAG_REGION_OVERFLOW], 1u);
             if (n > cap) atomicOr(&flags[FLAG_EXCHANGE_OVERFLOW], 1u);
         }
         if (i >= n) continue;

@@ -1,8 +1,19 @@
-// kernels_scan.hip -- the row-run sweep with SCAN-ALLOCATED record buffers (TA_OPT_IMPL = 6).
+// kernels_scan.hip -- THE sweep: one coalesced pass over the labelled volume (TA_OPT_IMPL = 0).
 //
-// Same decomposition, register-resident neighbours, workgroup LDS tables and flush as the row-run
-// sweep of kernels_rowrun.hip.  What changes is how the (sparse: ~2 of 64 lanes per compare) events
-// reach the dense 64-wide consumer:
+// One pass produces, per label, the exact integer accumulators behind SpatialImageAnalysis.volume /
+// boundingbox / center_of_mass / inertia_axis (SIA:1197-1292, 417-535) and, per unordered label pair, the
+// per-axis shared-face counts behind neighbors / cell_wall_area / wall_areas (SIA:538-660, 908-993).
+//
+// Work decomposition (memory axes: 0 slowest ... 2 fastest): workgroup = WAVES waves stacked along axis 1;
+// wave tile = RB rows x (64 lanes * VPL voxels) along axis 2; each lane keeps its RB x VPL voxels of the
+// current and the previous plane in VGPRs (16-byte loads, the next plane in flight) and the workgroup walks
+// `tile_planes` planes along axis 0.  Neighbours never leave the register file: axis 0 = the previous plane's
+// registers, axis 1 = the row above in the same lane (+ one halo row per wave), axis 2 = the previous voxel
+// of the strip (+ one DPP wave shift, + one halo voxel per row).  A label's voxels are summed as RUNS along
+// axis 2 inside a row (closed forms in the column), rows of one label from end to end are not even records.
+// No MFMA anywhere: integer compare / reduce work bound by the HBM read of the volume.
+//
+// How the (sparse: ~2 of 64 lanes per compare) events reach the dense 64-wide consumer:
 //   * per row every lane counts its events (one v_addc per compare), ONE packed DPP add-scan over the
 //     lanes gives each lane the offset of its first record, and a firing lane then stores its record at
 //     its own running offset (store + one v_add under the compare's mask).  No per-compare ballot /
@@ -50,6 +61,9 @@ struct __attribute__((aligned(16))) ScanLds {
     uint32_t lbox[LSLOTS * 8];
     uint32_t lkeys[LSLOTS];
     uint32_t pcnt[PSLOTS * 3];
+#ifdef TA_LDS_PAD
+    uint32_t pad_[TA_LDS_PAD];        // experiments only: fewer workgroups per CU
+#endif
 };
 
 // inclusive add-scan over the 64 lanes: row_shr 1,2,4,8 then the two row broadcasts
@@ -254,43 +268,271 @@ __device__ __forceinline__ void scan_load_strip(const bool EDGE, const T* row_c0
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // The plane in flight lives in registers the compiler never allocates: the kernels are compiled with
-// amdgpu_num_vgpr(TA_PIN_BASE), and v[TA_PIN_BASE ..] are named explicitly here: v104..v107 + 4 r = row r of the
+// amdgpu_num_vgpr(TA_PIN_BASE), and v[TA_PIN_BASE ..] are named explicitly here: the first quads = the rows of the
 // wave tile, the next quad = the row above it, then one register for lanes 0..RB-1: the voxel left of each row.
 // (Loading into ordinary asm outputs does not work: the register allocator copies a loop-carried output at the
 // back edge, i.e. reads it while the load is still in flight; accumulation registers make the compiler split the
 // unified file in halves.)
-#define TA_PIN_BASE 104
-#define TA_PIN_CLOBBERS "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", \
-                        "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124"
+#ifndef TA_PIN_BASE
+#define TA_PIN_BASE 104     // VGPRs the compiler may allocate; the 21 above them hold the plane in flight
+#endif
+#if TA_PIN_BASE == 104
+#define TA_PIN_CLOBBERS "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124"
+#define TA_PIN_Q0 "v[104:107]"
+#define TA_PIN_Q1 "v[108:111]"
+#define TA_PIN_Q2 "v[112:115]"
+#define TA_PIN_Q3 "v[116:119]"
+#define TA_PIN_Q4 "v[120:123]"
+#define TA_PIN_R0 "v104"
+#define TA_PIN_R1 "v105"
+#define TA_PIN_R2 "v106"
+#define TA_PIN_R3 "v107"
+#define TA_PIN_R4 "v108"
+#define TA_PIN_R5 "v109"
+#define TA_PIN_R6 "v110"
+#define TA_PIN_R7 "v111"
+#define TA_PIN_R8 "v112"
+#define TA_PIN_R9 "v113"
+#define TA_PIN_R10 "v114"
+#define TA_PIN_R11 "v115"
+#define TA_PIN_R12 "v116"
+#define TA_PIN_R13 "v117"
+#define TA_PIN_R14 "v118"
+#define TA_PIN_R15 "v119"
+#define TA_PIN_R16 "v120"
+#define TA_PIN_R17 "v121"
+#define TA_PIN_R18 "v122"
+#define TA_PIN_R19 "v123"
+#define TA_PIN_R20 "v124"
+#elif TA_PIN_BASE == 88
+#define TA_PIN_CLOBBERS "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108"
+#define TA_PIN_Q0 "v[88:91]"
+#define TA_PIN_Q1 "v[92:95]"
+#define TA_PIN_Q2 "v[96:99]"
+#define TA_PIN_Q3 "v[100:103]"
+#define TA_PIN_Q4 "v[104:107]"
+#define TA_PIN_R0 "v88"
+#define TA_PIN_R1 "v89"
+#define TA_PIN_R2 "v90"
+#define TA_PIN_R3 "v91"
+#define TA_PIN_R4 "v92"
+#define TA_PIN_R5 "v93"
+#define TA_PIN_R6 "v94"
+#define TA_PIN_R7 "v95"
+#define TA_PIN_R8 "v96"
+#define TA_PIN_R9 "v97"
+#define TA_PIN_R10 "v98"
+#define TA_PIN_R11 "v99"
+#define TA_PIN_R12 "v100"
+#define TA_PIN_R13 "v101"
+#define TA_PIN_R14 "v102"
+#define TA_PIN_R15 "v103"
+#define TA_PIN_R16 "v104"
+#define TA_PIN_R17 "v105"
+#define TA_PIN_R18 "v106"
+#define TA_PIN_R19 "v107"
+#define TA_PIN_R20 "v108"
+#elif TA_PIN_BASE == 80
+#define TA_PIN_CLOBBERS "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100"
+#define TA_PIN_Q0 "v[80:83]"
+#define TA_PIN_Q1 "v[84:87]"
+#define TA_PIN_Q2 "v[88:91]"
+#define TA_PIN_Q3 "v[92:95]"
+#define TA_PIN_Q4 "v[96:99]"
+#define TA_PIN_R0 "v80"
+#define TA_PIN_R1 "v81"
+#define TA_PIN_R2 "v82"
+#define TA_PIN_R3 "v83"
+#define TA_PIN_R4 "v84"
+#define TA_PIN_R5 "v85"
+#define TA_PIN_R6 "v86"
+#define TA_PIN_R7 "v87"
+#define TA_PIN_R8 "v88"
+#define TA_PIN_R9 "v89"
+#define TA_PIN_R10 "v90"
+#define TA_PIN_R11 "v91"
+#define TA_PIN_R12 "v92"
+#define TA_PIN_R13 "v93"
+#define TA_PIN_R14 "v94"
+#define TA_PIN_R15 "v95"
+#define TA_PIN_R16 "v96"
+#define TA_PIN_R17 "v97"
+#define TA_PIN_R18 "v98"
+#define TA_PIN_R19 "v99"
+#define TA_PIN_R20 "v100"
+#elif TA_PIN_BASE == 75
+#define TA_PIN_CLOBBERS "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95"
+#define TA_PIN_Q0 "v[75:78]"
+#define TA_PIN_Q1 "v[79:82]"
+#define TA_PIN_Q2 "v[83:86]"
+#define TA_PIN_Q3 "v[87:90]"
+#define TA_PIN_Q4 "v[91:94]"
+#define TA_PIN_R0 "v75"
+#define TA_PIN_R1 "v76"
+#define TA_PIN_R2 "v77"
+#define TA_PIN_R3 "v78"
+#define TA_PIN_R4 "v79"
+#define TA_PIN_R5 "v80"
+#define TA_PIN_R6 "v81"
+#define TA_PIN_R7 "v82"
+#define TA_PIN_R8 "v83"
+#define TA_PIN_R9 "v84"
+#define TA_PIN_R10 "v85"
+#define TA_PIN_R11 "v86"
+#define TA_PIN_R12 "v87"
+#define TA_PIN_R13 "v88"
+#define TA_PIN_R14 "v89"
+#define TA_PIN_R15 "v90"
+#define TA_PIN_R16 "v91"
+#define TA_PIN_R17 "v92"
+#define TA_PIN_R18 "v93"
+#define TA_PIN_R19 "v94"
+#define TA_PIN_R20 "v95"
+#elif TA_PIN_BASE == 72
+#define TA_PIN_CLOBBERS "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92"
+#define TA_PIN_Q0 "v[72:75]"
+#define TA_PIN_Q1 "v[76:79]"
+#define TA_PIN_Q2 "v[80:83]"
+#define TA_PIN_Q3 "v[84:87]"
+#define TA_PIN_Q4 "v[88:91]"
+#define TA_PIN_R0 "v72"
+#define TA_PIN_R1 "v73"
+#define TA_PIN_R2 "v74"
+#define TA_PIN_R3 "v75"
+#define TA_PIN_R4 "v76"
+#define TA_PIN_R5 "v77"
+#define TA_PIN_R6 "v78"
+#define TA_PIN_R7 "v79"
+#define TA_PIN_R8 "v80"
+#define TA_PIN_R9 "v81"
+#define TA_PIN_R10 "v82"
+#define TA_PIN_R11 "v83"
+#define TA_PIN_R12 "v84"
+#define TA_PIN_R13 "v85"
+#define TA_PIN_R14 "v86"
+#define TA_PIN_R15 "v87"
+#define TA_PIN_R16 "v88"
+#define TA_PIN_R17 "v89"
+#define TA_PIN_R18 "v90"
+#define TA_PIN_R19 "v91"
+#define TA_PIN_R20 "v92"
+#elif TA_PIN_BASE == 64
+#define TA_PIN_CLOBBERS "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84"
+#define TA_PIN_Q0 "v[64:67]"
+#define TA_PIN_Q1 "v[68:71]"
+#define TA_PIN_Q2 "v[72:75]"
+#define TA_PIN_Q3 "v[76:79]"
+#define TA_PIN_Q4 "v[80:83]"
+#define TA_PIN_R0 "v64"
+#define TA_PIN_R1 "v65"
+#define TA_PIN_R2 "v66"
+#define TA_PIN_R3 "v67"
+#define TA_PIN_R4 "v68"
+#define TA_PIN_R5 "v69"
+#define TA_PIN_R6 "v70"
+#define TA_PIN_R7 "v71"
+#define TA_PIN_R8 "v72"
+#define TA_PIN_R9 "v73"
+#define TA_PIN_R10 "v74"
+#define TA_PIN_R11 "v75"
+#define TA_PIN_R12 "v76"
+#define TA_PIN_R13 "v77"
+#define TA_PIN_R14 "v78"
+#define TA_PIN_R15 "v79"
+#define TA_PIN_R16 "v80"
+#define TA_PIN_R17 "v81"
+#define TA_PIN_R18 "v82"
+#define TA_PIN_R19 "v83"
+#define TA_PIN_R20 "v84"
+#elif TA_PIN_BASE == 59
+#define TA_PIN_CLOBBERS "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
+#define TA_PIN_Q0 "v[59:62]"
+#define TA_PIN_Q1 "v[63:66]"
+#define TA_PIN_Q2 "v[67:70]"
+#define TA_PIN_Q3 "v[71:74]"
+#define TA_PIN_Q4 "v[75:78]"
+#define TA_PIN_R0 "v59"
+#define TA_PIN_R1 "v60"
+#define TA_PIN_R2 "v61"
+#define TA_PIN_R3 "v62"
+#define TA_PIN_R4 "v63"
+#define TA_PIN_R5 "v64"
+#define TA_PIN_R6 "v65"
+#define TA_PIN_R7 "v66"
+#define TA_PIN_R8 "v67"
+#define TA_PIN_R9 "v68"
+#define TA_PIN_R10 "v69"
+#define TA_PIN_R11 "v70"
+#define TA_PIN_R12 "v71"
+#define TA_PIN_R13 "v72"
+#define TA_PIN_R14 "v73"
+#define TA_PIN_R15 "v74"
+#define TA_PIN_R16 "v75"
+#define TA_PIN_R17 "v76"
+#define TA_PIN_R18 "v77"
+#define TA_PIN_R19 "v78"
+#define TA_PIN_R20 "v79"
+#elif TA_PIN_BASE == 56
+#define TA_PIN_CLOBBERS "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76"
+#define TA_PIN_Q0 "v[56:59]"
+#define TA_PIN_Q1 "v[60:63]"
+#define TA_PIN_Q2 "v[64:67]"
+#define TA_PIN_Q3 "v[68:71]"
+#define TA_PIN_Q4 "v[72:75]"
+#define TA_PIN_R0 "v56"
+#define TA_PIN_R1 "v57"
+#define TA_PIN_R2 "v58"
+#define TA_PIN_R3 "v59"
+#define TA_PIN_R4 "v60"
+#define TA_PIN_R5 "v61"
+#define TA_PIN_R6 "v62"
+#define TA_PIN_R7 "v63"
+#define TA_PIN_R8 "v64"
+#define TA_PIN_R9 "v65"
+#define TA_PIN_R10 "v66"
+#define TA_PIN_R11 "v67"
+#define TA_PIN_R12 "v68"
+#define TA_PIN_R13 "v69"
+#define TA_PIN_R14 "v70"
+#define TA_PIN_R15 "v71"
+#define TA_PIN_R16 "v72"
+#define TA_PIN_R17 "v73"
+#define TA_PIN_R18 "v74"
+#define TA_PIN_R19 "v75"
+#define TA_PIN_R20 "v76"
+#else
+#error "no register names written out for this TA_PIN_BASE"
+#endif
 template <int Q>      // quad Q of the pinned registers <- 16 bytes at sbase + voff
 __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
-    if (Q == 0)      asm volatile("global_load_dwordx4 v[104:107], %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-    else if (Q == 1) asm volatile("global_load_dwordx4 v[108:111], %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-    else if (Q == 2) asm volatile("global_load_dwordx4 v[112:115], %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-    else if (Q == 3) asm volatile("global_load_dwordx4 v[116:119], %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-    else             asm volatile("global_load_dwordx4 v[120:123], %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+    if (Q == 0)      asm volatile("global_load_dwordx4 " TA_PIN_Q0 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+    else if (Q == 1) asm volatile("global_load_dwordx4 " TA_PIN_Q1 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+    else if (Q == 2) asm volatile("global_load_dwordx4 " TA_PIN_Q2 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+    else if (Q == 3) asm volatile("global_load_dwordx4 " TA_PIN_Q3 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+    else             asm volatile("global_load_dwordx4 " TA_PIN_Q4 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
 }
 template <typename T, int RB>
 __device__ __forceinline__ void issue_voxel(uint32_t voff, const void* sbase) {
     if (sizeof(T) == 4) {
-        if (RB == 4) asm volatile("global_load_dword v124, %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-        else         asm volatile("global_load_dword v116, %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+        if (RB == 4) asm volatile("global_load_dword " TA_PIN_R20 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+        else         asm volatile("global_load_dword " TA_PIN_R12 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
     } else {
-        if (RB == 4) asm volatile("global_load_ushort v124, %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-        else         asm volatile("global_load_ushort v116, %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+        if (RB == 4) asm volatile("global_load_ushort " TA_PIN_R20 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+        else         asm volatile("global_load_ushort " TA_PIN_R12 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
     }
 }
 // wait for every hand-issued load and move the plane into ordinary registers
+#define TA_RD(i, r) "v_mov_b32 %" #i ", " r "\n"
 template <int RB>
 __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {
     if (RB == 4) {
         asm volatile("s_waitcnt vmcnt(0)\n"
-                     "v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n v_mov_b32 %2, v106\n v_mov_b32 %3, v107\n"
-                     "v_mov_b32 %4, v108\n v_mov_b32 %5, v109\n v_mov_b32 %6, v110\n v_mov_b32 %7, v111\n"
-                     "v_mov_b32 %8, v112\n v_mov_b32 %9, v113\n v_mov_b32 %10, v114\n v_mov_b32 %11, v115\n"
-                     "v_mov_b32 %12, v116\n v_mov_b32 %13, v117\n v_mov_b32 %14, v118\n v_mov_b32 %15, v119\n"
-                     "v_mov_b32 %16, v120\n v_mov_b32 %17, v121\n v_mov_b32 %18, v122\n v_mov_b32 %19, v123\n"
-                     "v_mov_b32 %20, v124\n"
+                     TA_RD(0, TA_PIN_R0) TA_RD(1, TA_PIN_R1) TA_RD(2, TA_PIN_R2) TA_RD(3, TA_PIN_R3)
+                     TA_RD(4, TA_PIN_R4) TA_RD(5, TA_PIN_R5) TA_RD(6, TA_PIN_R6) TA_RD(7, TA_PIN_R7)
+                     TA_RD(8, TA_PIN_R8) TA_RD(9, TA_PIN_R9) TA_RD(10, TA_PIN_R10) TA_RD(11, TA_PIN_R11)
+                     TA_RD(12, TA_PIN_R12) TA_RD(13, TA_PIN_R13) TA_RD(14, TA_PIN_R14) TA_RD(15, TA_PIN_R15)
+                     TA_RD(16, TA_PIN_R16) TA_RD(17, TA_PIN_R17) TA_RD(18, TA_PIN_R18) TA_RD(19, TA_PIN_R19)
+                     TA_RD(20, TA_PIN_R20)
                      : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
                        "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
                        "=&v"(raw[RB > 2 ? 2 : 0].x), "=&v"(raw[RB > 2 ? 2 : 0].y), "=&v"(raw[RB > 2 ? 2 : 0].z), "=&v"(raw[RB > 2 ? 2 : 0].w),
@@ -299,16 +541,17 @@ __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l
                      :: "memory");
     } else {
         asm volatile("s_waitcnt vmcnt(0)\n"
-                     "v_mov_b32 %0, v104\n v_mov_b32 %1, v105\n v_mov_b32 %2, v106\n v_mov_b32 %3, v107\n"
-                     "v_mov_b32 %4, v108\n v_mov_b32 %5, v109\n v_mov_b32 %6, v110\n v_mov_b32 %7, v111\n"
-                     "v_mov_b32 %8, v112\n v_mov_b32 %9, v113\n v_mov_b32 %10, v114\n v_mov_b32 %11, v115\n"
-                     "v_mov_b32 %12, v116\n"
+                     TA_RD(0, TA_PIN_R0) TA_RD(1, TA_PIN_R1) TA_RD(2, TA_PIN_R2) TA_RD(3, TA_PIN_R3)
+                     TA_RD(4, TA_PIN_R4) TA_RD(5, TA_PIN_R5) TA_RD(6, TA_PIN_R6) TA_RD(7, TA_PIN_R7)
+                     TA_RD(8, TA_PIN_R8) TA_RD(9, TA_PIN_R9) TA_RD(10, TA_PIN_R10) TA_RD(11, TA_PIN_R11)
+                     TA_RD(12, TA_PIN_R12)
                      : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
                        "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
                        "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
                      :: "memory");
     }
 }
+#undef TA_RD
 template <typename T, int VPL>
 __device__ __forceinline__ void unpack_strip(const u32x4& x, uint32_t (&dst)[VPL]) {
     if (sizeof(T) == 4) {
@@ -653,7 +896,7 @@ static ScanSplit scan_split(const SweepArgs& a, int itemsize) {
 }
 
 template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE>
-__global__ void __launch_bounds__(WAVES * 64, TA_MINWAVES) __attribute__((amdgpu_num_vgpr(TA_PIN_BASE))) scan_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_PIN_BASE))) scan_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
     constexpr int NW = MOM2 ? 6 : 2;
     constexpr int TC = 64 * VPL, TB = WAVES * RB;
     static_assert(TB <= 16 && TC <= 512, "packed LDS moment words assume <= 16 rows x 512 columns per tile");
@@ -723,6 +966,13 @@ static void launch_scan_t(hipStream_t s, const SweepArgs& a, uint32_t fm) {
     else if (!adj && mom2) launch_scan_tt<T, VPL, RB, false, true>(s, a);
     else                   launch_scan_tt<T, VPL, RB, false, false>(s, a);
 }
+
+uint64_t sweep_grid_size(const SweepArgs& a, int itemsize) {
+    const ScanSplit sp = itemsize == 2 ? scan_split<8, 2>(a, 2) : scan_split<4, TA_RB32>(a, 4);
+    return (uint64_t)sp.tiles_c * sp.tiles_b * sp.nbands;
+}
+int sweep_default_tile_planes() { return 32; }   // 64 planes start to overflow the 128-slot label table
+int sweep_max_tile_planes() { return MAX_TILE_PLANES; }
 
 void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask) {
     if (itemsize == 2) launch_scan_t<uint16_t, 8, 2>(s, a, feature_mask);

@@ -77,13 +77,10 @@ struct ta_ctx {
 
     // adjacency
     DevBuf pkeys, pfaces, out_keys, out_faces, small;   // small: flags[NFLAGS] | cursor | maxlabel
-    DevBuf split_f, split_r, split_hdr;                 // record regions of the split path (TA_OPT_IMPL = 2)
     DevBuf hot_rows;                                    // [workgroups][16] private rows of the hot label
-    DevBuf rle_rec, rle_dir, rle_hdr;                   // RLE path (TA_OPT_IMPL = 5): run records, row directory, counts
     DevBuf wall_counts;                                 // wall voxels: per-chunk record counts, then offsets
     int64_t wall_records = -1;                          // result of the last ta_wall_voxels_count, -1 = none
     double wall_ms = 0.0;
-    bool split_failed = false;                          // a region overflowed on this volume: use the fused sweep
     int pair_log2 = 0;                                  // current table log2 capacity
     int opt_pair_log2 = 0;
     bool table_clean = false;
@@ -163,9 +160,8 @@ int run_extract(ta_ctx* c) {
     a.flags = flags_dev(c);
     uint64_t* hot_rows = nullptr;
     uint64_t nwg = 0;
-    const bool rowrun = c->impl == 3 || c->impl == 6 || (c->impl == 0 && !(c->feature_mask & TA_F_ADJACENCY));
-    const bool rle = c->impl == 5 && !c->split_failed && c->first_owned == 0;
-    if ((rowrun && !(c->feature_mask & TA_F_ADJACENCY)) || rle) {     // the kernels that use the private hot-label rows
+    const bool adj_wanted = c->feature_mask & TA_F_ADJACENCY;
+    if (c->impl == 0 && !adj_wanted) {           // the sweep without adjacency keeps a private row per workgroup for the hot label
         nwg = ta::sweep_grid_size(a, c->itemsize);
         int rc0 = c->hot_rows.reserve(nwg * ta::HOTW * 8);
         if (rc0 != TA_OK) return rc0;
@@ -180,39 +176,8 @@ int run_extract(ta_ctx* c) {
     }
     ta::launch_init_accumulators(c->stream, c->sums, c->boxes, nlabels, flags_dev(c), cursor_dev(c), hot_rows);
     TA_HIP(hipEventRecord(c->ev[1], c->stream));
-    if (c->impl == 1) {
-        ta::launch_naive(c->stream, a, c->itemsize, c->feature_mask);
-    } else if (c->impl == 2 && !c->split_failed) {
-        ta::SplitArgs sa;
-        sa.a = a;
-        uint64_t wave_tiles = 0;
-        ta::split_region_shape(a, c->itemsize, &wave_tiles, &sa.fcap, &sa.rcap);
-        int rc;
-        if ((rc = c->split_f.reserve(wave_tiles * sa.fcap * 8)) != TA_OK) return rc;
-        if ((rc = c->split_r.reserve(wave_tiles * sa.rcap * 8)) != TA_OK) return rc;
-        if ((rc = c->split_hdr.reserve(wave_tiles * 16)) != TA_OK) return rc;
-        sa.frec = (uint64_t*)c->split_f.p; sa.rrec = (uint64_t*)c->split_r.p; sa.rhdr = (uint32_t*)c->split_hdr.p;
-        ta::launch_split(c->stream, sa, c->itemsize, c->feature_mask);
-    } else if (rle) {
-        ta::RleArgs ra;
-        ra.a = a;
-        uint64_t wave_tiles = 0; uint32_t drows = 0;
-        ta::rle_region_shape(a, c->itemsize, &wave_tiles, &ra.rcap, &drows);
-        int rc;
-        if ((rc = c->rle_rec.reserve(wave_tiles * 3ull * ra.rcap * 4)) != TA_OK) return rc;
-        if ((rc = c->rle_dir.reserve(wave_tiles * (uint64_t)drows * 16)) != TA_OK) return rc;
-        if ((rc = c->rle_hdr.reserve(wave_tiles * 4 + 16)) != TA_OK) return rc;
-        ra.rle = (uint32_t*)c->rle_rec.p; ra.dir = (uint4*)c->rle_dir.p; ra.hdr = (uint32_t*)c->rle_hdr.p;
-        ta::launch_rle(c->stream, ra, c->itemsize, c->feature_mask);
-    } else if (c->impl == 6) {
-        ta::launch_scan(c->stream, a, c->itemsize, c->feature_mask);
-    } else if (c->impl == 3 || (c->impl == 0 && !adj)) {
-        // default: runs along the contiguous axis when no adjacency is asked for (moments-only sets run
-        // at 55-60 % of the HBM peak there), the fused axis-0 sweep when it is (equal on C4, faster on C3)
-        ta::launch_rowrun(c->stream, a, c->itemsize, c->feature_mask);
-    } else {
-        ta::launch_sweep(c->stream, a, c->itemsize, c->feature_mask);
-    }
+    if (c->impl == 1) ta::launch_naive(c->stream, a, c->itemsize, c->feature_mask);
+    else              ta::launch_scan(c->stream, a, c->itemsize, c->feature_mask);
     if (hot_rows) ta::launch_hot_reduce(c->stream, a, c->itemsize, hot_rows, (uint32_t)nwg);
     TA_HIP(hipEventRecord(c->ev[2], c->stream));
     if (adj)
@@ -236,10 +201,6 @@ int finish_extract(ta_ctx* c) {
             return fail(TA_ERANGE, "a rank saw a label above max_label=%u", c->max_label);
         if (c->h_small[ta::FLAG_EXCHANGE_OVERFLOW])
             return fail(TA_ECAPACITY, "an exchange block was too small for a rank's pair list");
-        if (c->h_small[ta::FLAG_REGION_OVERFLOW]) {
-            c->split_failed = true;                       // the redo runs the fused sweep on this volume
-            return fail(TA_ECAPACITY, "a record region of the split path overflowed on some rank");
-        }
         if (c->h_small[ta::FLAG_PAIR_OVERFLOW])
             return fail(TA_ECAPACITY, "adjacency table overflow on some rank (2^%d slots here)", c->pair_log2);
         c->npairs = (int64_t)c->h_small[ta::NFLAGS];
@@ -250,12 +211,6 @@ int finish_extract(ta_ctx* c) {
         TA_HIP(hipStreamSynchronize(c->stream));
         if (c->h_small[ta::FLAG_RANGE])
             return fail(TA_ERANGE, "the volume holds a label above max_label=%u", c->max_label);
-        if (c->h_small[ta::FLAG_REGION_OVERFLOW]) {      // split path: denser than tissue, use the fused sweep
-            c->split_failed = true;
-            int rc = run_extract(c);
-            if (rc != TA_OK) return rc;
-            continue;
-        }
         if (!c->h_small[ta::FLAG_PAIR_OVERFLOW]) {
             c->npairs = (c->feature_mask & TA_F_ADJACENCY) ? (int64_t)c->h_small[ta::NFLAGS] : 0;
             c->checked = true;
@@ -316,9 +271,8 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     c->owned_vol.release(); c->own_sums.release(); c->own_boxes.release();
     c->pkeys.release(); c->pfaces.release(); c->out_keys.release(); c->out_faces.release();
     c->small.release();
-    c->split_f.release(); c->split_r.release(); c->split_hdr.release(); c->hot_rows.release();
+    c->hot_rows.release();
     c->wall_counts.release();
-    c->rle_rec.release(); c->rle_dir.release(); c->rle_hdr.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -346,7 +300,7 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
     if (!c) return fail(TA_EINVAL, "ctx is NULL");
     switch (key) {
         case TA_OPT_IMPL:
-            if (value < 0 || value > 6) return fail(TA_EINVAL, "TA_OPT_IMPL must be in [0,6]");
+            if (value < 0 || value > 1) return fail(TA_EINVAL, "TA_OPT_IMPL must be 0 (sweep) or 1 (per-voxel atomics)");
             c->impl = (int)value; return TA_OK;
         case TA_OPT_TILE_PLANES:
             if (value < 0 || value > ta::sweep_max_tile_planes()) return fail(TA_EINVAL, "TA_OPT_TILE_PLANES must be in [0,%d]", ta::sweep_max_tile_planes());
@@ -408,7 +362,6 @@ TA_API int ta_volume_set(ta_ctx* c, const void* host_ptr, int itemsize, const in
     TA_HIP(hipMemcpyAsync(c->owned_vol.p, host_ptr, bytes, hipMemcpyHostToDevice, c->stream));
     TA_HIP(hipStreamSynchronize(c->stream));   // the host buffer may be freed after return
     c->vol = c->owned_vol.p;
-    c->split_failed = false;
     c->wall_records = -1;
     c->itemsize = itemsize;
     for (int k = 0; k < 3; ++k) { c->perm[k] = perm[k]; c->mdims[k] = dims[perm[k]]; }
@@ -428,7 +381,6 @@ TA_API int ta_volume_set_device(ta_ctx* c, const void* dev_ptr, int itemsize, co
     if (a0_origin < 0) return fail(TA_EINVAL, "a0_origin must be >= 0");
     if (((uintptr_t)dev_ptr % itemsize) != 0) return fail(TA_EINVAL, "device pointer is not aligned to the label type");
     c->vol = dev_ptr;
-    c->split_failed = false;
     c->wall_records = -1;
     c->itemsize = itemsize;
     for (int k = 0; k < 3; ++k) { c->perm[k] = k; c->mdims[k] = buf_dims[k]; }
@@ -460,7 +412,6 @@ TA_API int ta_volume_relabel(ta_ctx* c, const uint32_t* lut, uint32_t lut_len) {
     d.release();
     if (e != hipSuccess) return fail(TA_EHIP, "relabel: %s", hipGetErrorString(e));
     c->extracted = c->checked = false;
-    c->split_failed = false;
     return TA_OK;
 }
 

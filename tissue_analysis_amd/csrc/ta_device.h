@@ -15,13 +15,13 @@ constexpr int NBOX = 6;                             // min0,min1,min2,-max0,-max
 
 // flag words written by kernels, read back by the host after the stream drains
 enum { FLAG_RANGE = 0, FLAG_PAIR_OVERFLOW = 1, FLAG_LDS_LABEL_SPILL = 2, FLAG_LDS_PAIR_SPILL = 3,
-       FLAG_EXCHANGE_OVERFLOW = 4, FLAG_REGION_OVERFLOW = 5, NFLAGS = 16 };
+       FLAG_EXCHANGE_OVERFLOW = 4, NFLAGS = 16 };
 
 // Exchange block of one rank (multi-GPU adjacency merge), u64 words:
 //   [0] pair count n (may exceed the capacity: receivers flag the overflow)   [1] status bits
 //   [2 .. 2+cap) keys, EMPTY_KEY padded        [2+cap .. 2+4*cap) faces[cap][3]
 constexpr int XHDR = 2;
-constexpr uint64_t XSTATUS_RANGE = 1, XSTATUS_PAIR_OVERFLOW = 2, XSTATUS_REGION_OVERFLOW = 4;
+constexpr uint64_t XSTATUS_RANGE = 1, XSTATUS_PAIR_OVERFLOW = 2;
 
 struct PairTable {           // device-global open-addressing hash: key = lo<<32|hi
     uint64_t* keys;          // [cap], EMPTY_KEY when free
@@ -48,15 +48,6 @@ struct SweepArgs {
 // init_kernel and fetched with a scalar load where it is needed.
 constexpr int HOTW = 16;             // u64 words of a hot row: sums u64[NSUM] | boxes i32[NBOX] | padding
 constexpr int HOT_PTR_WORD = NFLAGS + 2;   // uint32 index into the flags buffer, 8-byte aligned
-
-// split path (emit kernel -> record regions in HBM -> reduce kernel); one region per wave tile
-struct SplitArgs {
-    SweepArgs a;
-    uint64_t* frec;          // [wave tiles][fcap] face records {voxel, neighbour | axis << 30}
-    uint64_t* rrec;          // [wave tiles][rcap] run records  {label, c | b << 10 | a0 << 14 | n << 20}
-    uint32_t* rhdr;          // [wave tiles][4]   faces, runs, uniform label (or a sentinel), planes - 1
-    uint32_t fcap, rcap;
-};
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -125,15 +116,6 @@ __device__ inline void run_add_global(const SweepArgs& A, uint32_t label, uint64
     atomicMin(box + 1, (int32_t)b);   atomicMin(box + 4, -(int32_t)b);
     atomicMin(box + 2, (int32_t)c);   atomicMin(box + 5, -(int32_t)c);
 }
-
-// RLE path (kernels_rle.hip): the row-run sweep keeps its run records, the adjacency is computed from them
-struct RleArgs {
-    SweepArgs a;
-    uint32_t* rle;           // [wave tiles][3][rcap]: closing label | voxel to the right | c0 | n << 9 | b << 19 | a << 23
-    uint4* dir;              // [wave tiles][tile_planes * RB] per row: first record, records, uniform label, -
-    uint32_t* hdr;           // [wave tiles] records written
-    uint32_t rcap;
-};
 
 template <typename T>
 __device__ __forceinline__ uint32_t load_label(const void* vol, int64_t idx) {

@@ -31,16 +31,8 @@ void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3],
                   int64_t a_count, const int32_t* seeds_dev, const int32_t grid[3],
                   const int64_t* ell_dev);
 
-// kernels_sweep.hip
-void launch_sweep(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);
-// split path: sizes of the record regions for a volume (wave tiles, face / run records per tile)
-void split_region_shape(const SweepArgs& a, int itemsize, uint64_t* wave_tiles, uint32_t* fcap, uint32_t* rcap);
-void launch_split(hipStream_t s, const SplitArgs& a, int itemsize, uint32_t feature_mask);
-void launch_rowrun(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);   // kernels_rowrun.hip
-void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);     // kernels_scan.hip
-// kernels_rle.hip
-void rle_region_shape(const SweepArgs& a, int itemsize, uint64_t* wave_tiles, uint32_t* rcap, uint32_t* dir_rows);
-void launch_rle(hipStream_t s, const RleArgs& p, int itemsize, uint32_t feature_mask);
+// kernels_scan.hip -- the sweep
+void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);
 uint64_t sweep_grid_size(const SweepArgs& a, int itemsize);   // workgroups of any of the sweep kernels
 int sweep_default_tile_planes();
 int sweep_max_tile_planes();

@@ -1,6 +1,7 @@
-// ta_sweep_common.h -- pieces shared by the sweep kernels (kernels_sweep.hip, kernels_rowrun.hip):
-// tuning constants, register-level helpers (DPP shift, mask prefix, strip loads), the workgroup LDS
-// hash tables (label -> packed tile-local moments + bbox, pair -> per-axis face counts) and their flush.
+// ta_sweep_common.h -- pieces of the sweep kernel (kernels_scan.hip) that are not its hot loop:
+// tuning constants, the DPP lane shift, tile-local sum records, the global spill paths, the private
+// hot-label rows and the flush of the workgroup LDS tables (label -> packed tile-local moments + bbox,
+// pair -> per-axis face counts) with global atomics.
 #pragma once
 #include "ta_kernels.h"
 
@@ -15,23 +16,13 @@ namespace ta {
 #ifndef TA_RB32
 #define TA_RB32 4
 #endif
-#ifndef TA_QCAP
-#define TA_QCAP 256
-#endif
 #ifndef TA_PSLOTS
 #define TA_PSLOTS 512
 #endif
 #ifndef TA_LSLOTS
 #define TA_LSLOTS 128
 #endif
-#ifndef TA_PREFETCH
-#define TA_PREFETCH 1
-#endif
-#ifndef TA_MINWAVES
-#define TA_MINWAVES 4             // waves per SIMD the register allocator must leave room for
-#endif
 constexpr int WAVES = TA_WAVES;   // waves per workgroup, stacked along axis 1
-constexpr int QCAP = TA_QCAP;     // per-wave ring capacity (records); one block adds <= 64
 constexpr int LSLOTS = TA_LSLOTS; // label table slots per workgroup
 constexpr int PSLOTS = TA_PSLOTS; // pair table slots per workgroup
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
@@ -45,33 +36,6 @@ constexpr uint32_t LABEL_LIMIT = 1u << 28;    // max_label < 2^28: the two top b
 __device__ __forceinline__ uint32_t lane_shr1(uint32_t src, uint32_t lane0_value) {
     // lane i <- src of lane i-1 ; lane 0 keeps lane0_value   (DPP wave_shr:1)
     return (uint32_t)__builtin_amdgcn_update_dpp((int)lane0_value, (int)src, 0x138, 0xf, 0xf, false);
-}
-
-__device__ __forceinline__ uint32_t mbcnt64(uint64_t m) {
-    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// ---- strip loads ---------------------------------------------------------------------------
-// `row_c0` points at the wave's first voxel of the row (wave-uniform, lives in SGPRs); lanes add a
-// 32-bit byte offset, so the 16-byte loads use the saddr + voffset form and no 64-bit VGPR address.
-template <typename T, int VPL>
-__device__ __forceinline__ void load_strip(const bool EDGE, const T* row_c0, bool row_ok, uint32_t lane_off,
-                                           int64_t c, int64_t n2, uint32_t (&dst)[VPL]) {
-    if (!EDGE) {
-        const uint4 x = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(row_c0) + lane_off);
-        if (sizeof(T) == 4) {
-            dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
-        } else {
-            dst[0] = x.x & 0xffffu; dst[1] = x.x >> 16; dst[2] = x.y & 0xffffu; dst[3] = x.y >> 16;
-            dst[4 % VPL] = x.z & 0xffffu; dst[5 % VPL] = x.z >> 16;
-            dst[6 % VPL] = x.w & 0xffffu; dst[7 % VPL] = x.w >> 16;
-        }
-    } else {
-        const T* lane_p = reinterpret_cast<const T*>(reinterpret_cast<const char*>(row_c0) + lane_off);
-#pragma unroll
-        for (int j = 0; j < VPL; ++j)
-            dst[j] = (row_ok && c + j < n2) ? (uint32_t)lane_p[j] : INVALID_LABEL;
-    }
 }
 
 // one voxel at a wave-uniform address through the scalar cache (SMEM): no VGPR, no vector-memory slot
@@ -122,81 +86,6 @@ static __device__ __noinline__ void pair_spill_global(PairTable pt, uint32_t* fl
                                                uint32_t axis, uint32_t count) {
     atomicAdd(&flags[FLAG_LDS_PAIR_SPILL], 1u);
     pair_add_global(pt, lo, hi, axis == 0 ? count : 0, axis == 1 ? count : 0, axis == 2 ? count : 0, flags);
-}
-
-// ---- workgroup-shared LDS tables -----------------------------------------------------------
-struct TileFrame { uint64_t A0, B0, C0; };     // origin of the tile-local frame
-
-template <bool MOM2, typename LDS, typename SUMS>
-__device__ __forceinline__ void lds_label_add(const SweepArgs& A, LDS& S, const TileFrame& F, uint32_t label,
-                                              const SUMS& L, uint32_t mna, uint32_t mxa, uint32_t mnb,
-                                              uint32_t mxb, uint32_t mnc, uint32_t mxc) {
-    constexpr int NW = MOM2 ? 6 : 2;
-    // Fibonacci hashing modulo 2^24 on the full-rate 24-bit multiplier: top bits of the low 24 product bits
-    uint32_t h = (__umul24(label, 0x9E3779u) >> (24 - LSLOTS_LOG2)) & (LSLOTS - 1);
-    int slot = -1;
-#pragma nounroll
-    for (int probe = 0; probe < LPROBE; ++probe) {
-        uint32_t k = S.lkeys[h];
-        if (k == INVALID_LABEL) {
-            k = atomicCAS(&S.lkeys[h], INVALID_LABEL, label);
-            if (k == INVALID_LABEL) k = label;
-        }
-        if (k == label) { slot = (int)h; break; }
-        h = (h + 1) & (LSLOTS - 1);
-    }
-    if (slot >= 0) {
-        unsigned long long* row = (unsigned long long*)&S.lsum[slot * NW];
-        atomicAdd(row + 0, (unsigned long long)((uint64_t)L.n | ((uint64_t)L.sb << 32)));
-        atomicAdd(row + 1, (unsigned long long)((uint64_t)L.sa | ((uint64_t)L.sc << 32)));
-        if (MOM2) {
-            atomicAdd(row + 2, (unsigned long long)((uint64_t)L.saa | ((uint64_t)L.sab << 32)));
-            atomicAdd(row + 3, (unsigned long long)((uint64_t)L.sbb | ((uint64_t)L.sbc << 32)));
-            atomicAdd(row + (MOM2 ? 4 : 0), (unsigned long long)L.sac);
-            atomicAdd(row + (MOM2 ? 5 : 0), (unsigned long long)L.scc);
-        }
-        // bounding box: read first, touch the atomics only when this contribution extends it
-        uint32_t* box = &S.lbox[slot * 8];
-        const uint4 cur = *reinterpret_cast<const uint4*>(box);          // min a,b,c | max a
-        const uint2 cur2 = *reinterpret_cast<const uint2*>(box + 4);     // max b,c
-        if (mna < cur.x) atomicMin(box + 0, mna);
-        if (mnb < cur.y) atomicMin(box + 1, mnb);
-        if (mnc < cur.z) atomicMin(box + 2, mnc);
-        if (mxa > cur.w) atomicMax(box + 3, mxa);
-        if (mxb > cur2.x) atomicMax(box + 4, mxb);
-        if (mxc > cur2.y) atomicMax(box + 5, mxc);
-    } else {                                       // table full: straight to the global rows
-        // copies made HERE so that only this cold branch (not the hot path) has address-taken locals
-        LocalSums Lc;
-        Lc.n = L.n; Lc.sa = L.sa; Lc.sb = L.sb; Lc.sc = L.sc; Lc.saa = L.saa; Lc.sab = L.sab;
-        Lc.sac = L.sac; Lc.sbb = L.sbb; Lc.sbc = L.sbc; Lc.scc = L.scc;
-        uint32_t bx[6];
-        bx[0] = mna; bx[1] = mnb; bx[2] = mnc; bx[3] = mxa; bx[4] = mxb; bx[5] = mxc;
-        label_spill_global(A.sums, A.boxes, A.flags, A.max_label, label, &Lc, F.A0, F.B0, F.C0, bx);
-    }
-}
-
-template <typename LDS>
-__device__ __forceinline__ void lds_pair_add(const SweepArgs& A, LDS& S, uint32_t a, uint32_t b,
-                                             uint32_t axis, uint32_t count) {
-    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
-    const uint64_t key = ((uint64_t)lo << 32) | hi;
-    uint32_t h = __umul24(lo, 0x9E3779u) + __umul24(hi, 0x85EBCBu);     // two full-rate 24-bit multiplies, modulo 2^24
-    h = (h >> (24 - PSLOTS_LOG2)) & (PSLOTS - 1);
-    int slot = -1;
-#pragma nounroll
-    for (int probe = 0; probe < PPROBE; ++probe) {
-        uint64_t k = S.pkeys[h];
-        if (k == EMPTY_KEY) {
-            k = atomicCAS((unsigned long long*)&S.pkeys[h], (unsigned long long)EMPTY_KEY,
-                          (unsigned long long)key);
-            if (k == EMPTY_KEY) k = key;
-        }
-        if (k == key) { slot = (int)h; break; }
-        h = (h + 1) & (PSLOTS - 1);
-    }
-    if (slot >= 0) atomicAdd(&S.pcnt[slot * 3 + axis], count);
-    else pair_spill_global(A.pairs, A.flags, lo, hi, axis, count);
 }
 
 // sum_{x=x0}^{x0+n-1} x  and  x^2  (exact, u64)
@@ -278,40 +167,6 @@ template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS>
 __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const int tid, const uint64_t A0,
                                              const uint64_t B0, const uint64_t C0, const uint32_t hot) {
     flush_tables<NW, ADJ, MOM2, HOT, LDS>(A, S, tid, A0, B0, C0, hot, blockIdx.x);
-}
-
-// ---- shared by the row-run kernels (kernels_rowrun.hip, kernels_rle.hip) -----------------------
-// inclusive max-scan over the 64 lanes (identity 0): row_shr 1,2,4,8 then the two row broadcasts
-__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x) {
-#define TA_DPP_MAX(ctrl, rmask)                                                                   \
-    { const uint32_t y_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, false); \
-      x = x > y_ ? x : y_; }
-    TA_DPP_MAX(0x111, 0xf) TA_DPP_MAX(0x112, 0xf) TA_DPP_MAX(0x114, 0xf) TA_DPP_MAX(0x118, 0xf)
-    TA_DPP_MAX(0x142, 0xa) TA_DPP_MAX(0x143, 0xc)
-#undef TA_DPP_MAX
-    return x;
-}
-
-// one run [c0, c0+n) of a row (tile-local a, b): ten sums, every term < 2^32, every factor < 2^24
-template <bool MOM2, typename LDS>
-__device__ __forceinline__ void consume_row_run(const SweepArgs& A, LDS& S, const TileFrame& F, uint32_t label,
-                                                uint32_t code) {
-    const uint32_t c0 = code & 511u, n = (code >> 9) & 1023u, bl = (code >> 19) & 15u, al = (code >> 23) & 63u;
-    if (label >= LABEL_LIMIT || n == 0u) return;
-    const uint32_t t1 = __umul24(n, n - 1u);                                 // n (n - 1), even
-    const uint32_t nc0 = __umul24(n, c0);
-    const uint32_t sc = nc0 + (t1 >> 1);                                     // sum c over the run
-    const uint32_t na = __umul24(n, al), nb = __umul24(n, bl);
-    RunSums L;
-    L.n = n; L.sa = na; L.sb = nb; L.sc = sc;
-    if (MOM2) {
-        L.saa = __umul24(na, al); L.sab = __umul24(na, bl); L.sbb = __umul24(nb, bl);
-        L.sac = __umul24(al, sc); L.sbc = __umul24(bl, sc);
-        L.scc = __umul24(nc0, c0) + __umul24(c0, t1) + __umul24(t1 >> 1, 2u * n - 1u) / 3u;
-    } else {
-        L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
-    }
-    lds_label_add<MOM2, LDS, RunSums>(A, S, F, label, L, al, al, bl, bl, c0, c0 + n - 1u);
 }
 
 }  // namespace ta
