@@ -48,19 +48,21 @@ constexpr uint32_t NO_ROW = 0xFFFFFFFFu;                // code of the sentinel:
 
 typedef __attribute__((address_space(3))) uint32_t* lds_u32;
 
+template <bool ADJ>
 struct __attribute__((aligned(16))) ScanWaveLds {
-    uint2 frec[FCAP];                                   // faces of axis 0/1: voxel, neighbour | axis << 30
+    uint2 frec[ADJ ? FCAP : 1];                         // faces of axis 0/1: voxel, neighbour | axis << 30
     uint32_t cqv[RCAP + 1], cql[RCAP + 1], cqc[RCAP + 1];   // runs; record i lives in slot i + 1, slot 0 = sentinel / carry
 };
 
-template <int NW>
+template <int NW, bool ADJ>
 struct __attribute__((aligned(16))) ScanLds {
-    ScanWaveLds wave[WAVES];
+    ScanWaveLds<ADJ> wave[WAVES];
     uint64_t lsum[LSLOTS * NW];
-    uint64_t pkeys[PSLOTS];
+    uint64_t pkeys[ADJ ? PSLOTS : 2];
     uint32_t lbox[LSLOTS * 8];
     uint32_t lkeys[LSLOTS];
-    uint32_t pcnt[PSLOTS * 3];
+    uint32_t pcnt[ADJ ? PSLOTS * 3 : 1];
+    uint32_t frame[4];                // origin (axes 0, 1, 2) of the tile-local coordinates: only the spill paths need it
 #ifdef TA_LDS_PAD
     uint32_t pad_[TA_LDS_PAD];        // experiments only: fewer workgroups per CU
 #endif
@@ -95,7 +97,7 @@ __device__ __forceinline__ const SweepArgs* kernarg_args(const SweepArgs& by_val
 }
 
 template <bool MOM2, typename LDS, typename SUMS>
-__device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S, uint32_t A0, uint32_t B0, uint32_t C0,
+__device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S,
                                                uint32_t label, const SUMS& L, uint32_t mna, uint32_t mxa, uint32_t mnb,
                                                uint32_t mxb, uint32_t mnc, uint32_t mxc) {
     constexpr int NW = MOM2 ? 6 : 2;
@@ -138,7 +140,7 @@ __device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S, uint
         Lc.sac = L.sac; Lc.sbb = L.sbb; Lc.sbc = L.sbc; Lc.scc = L.scc;
         uint32_t bx[6];
         bx[0] = mna; bx[1] = mnb; bx[2] = mnc; bx[3] = mxa; bx[4] = mxb; bx[5] = mxc;
-        label_spill_global(A->sums, A->boxes, A->flags, A->max_label, label, &Lc, A0, B0, C0, bx);
+        label_spill_global(A->sums, A->boxes, A->flags, A->max_label, label, &Lc, S.frame[0], S.frame[1], S.frame[2], bx);
     }
 }
 
@@ -168,7 +170,7 @@ __device__ __forceinline__ void scan_pair_add(const SweepArgs* kp, LDS& S, uint3
 
 // one run [s, k) of a row (tile-local a, b): ten sums, every term < 2^32, every factor < 2^24
 template <bool MOM2, typename LDS>
-__device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S, uint32_t A0, uint32_t B0, uint32_t C0,
+__device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S,
                                                  const bool EDGE, uint32_t label, uint32_t s, uint32_t code) {
     const uint32_t c0 = s, k = code & 1023u, bl = (code >> 10) & 15u, al = (code >> 14) & 63u;
     const uint32_t n = k - c0;
@@ -191,12 +193,12 @@ __device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S, ui
     } else {
         L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
     }
-    scan_label_add<MOM2, LDS, RunSums>(kp, S, A0, B0, C0, label, L, al, al, bl, bl, c0, k - 1u);
+    scan_label_add<MOM2, LDS, RunSums>(kp, S, label, L, al, al, bl, bl, c0, k - 1u);
 }
 
 // Drain both buffers of a wave completely, 64 records per pass, every lane busy but in the last pass.
 template <bool ADJ, bool MOM2, typename LDS>
-__device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S, uint32_t A0, uint32_t B0, uint32_t C0,
+__device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
                                               const bool EDGE, int w, int lane, uint32_t& fcount, uint32_t& rcount) {
     auto& W = S.wave[w];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -222,7 +224,7 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S, uint3
         if (idx < rcount) {
             if (ADJ && v < LABEL_LIMIT && label < LABEL_LIMIT) scan_pair_add(kp, S, label, v, 2u);
             const uint32_t s = ((prev ^ code) & ROWID_MASK) == 0u ? (prev & 1023u) : 0u;
-            consume_scan_run<MOM2, LDS>(kp, S, A0, B0, C0, EDGE, label, s, code);
+            consume_scan_run<MOM2, LDS>(kp, S, EDGE, label, s, code);
         }
     }
     if (rcount) {
@@ -268,290 +270,74 @@ __device__ __forceinline__ void scan_load_strip(const bool EDGE, const T* row_c0
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 // The plane in flight lives in registers the compiler never allocates: the kernels are compiled with
-// amdgpu_num_vgpr(TA_PIN_BASE), and v[TA_PIN_BASE ..] are named explicitly here: the first quads = the rows of the
+// amdgpu_num_vgpr(BASE), and v[BASE ..] are named explicitly in Pin<BASE>: the first quads = the rows of the
 // wave tile, the next quad = the row above it, then one register for lanes 0..RB-1: the voxel left of each row.
 // (Loading into ordinary asm outputs does not work: the register allocator copies a loop-carried output at the
 // back edge, i.e. reads it while the load is still in flight; accumulation registers make the compiler split the
 // unified file in halves.)
-#ifndef TA_PIN_BASE
-#define TA_PIN_BASE 104     // VGPRs the compiler may allocate; the 21 above them hold the plane in flight
-#endif
-#if TA_PIN_BASE == 104
-#define TA_PIN_CLOBBERS "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124"
-#define TA_PIN_Q0 "v[104:107]"
-#define TA_PIN_Q1 "v[108:111]"
-#define TA_PIN_Q2 "v[112:115]"
-#define TA_PIN_Q3 "v[116:119]"
-#define TA_PIN_Q4 "v[120:123]"
-#define TA_PIN_R0 "v104"
-#define TA_PIN_R1 "v105"
-#define TA_PIN_R2 "v106"
-#define TA_PIN_R3 "v107"
-#define TA_PIN_R4 "v108"
-#define TA_PIN_R5 "v109"
-#define TA_PIN_R6 "v110"
-#define TA_PIN_R7 "v111"
-#define TA_PIN_R8 "v112"
-#define TA_PIN_R9 "v113"
-#define TA_PIN_R10 "v114"
-#define TA_PIN_R11 "v115"
-#define TA_PIN_R12 "v116"
-#define TA_PIN_R13 "v117"
-#define TA_PIN_R14 "v118"
-#define TA_PIN_R15 "v119"
-#define TA_PIN_R16 "v120"
-#define TA_PIN_R17 "v121"
-#define TA_PIN_R18 "v122"
-#define TA_PIN_R19 "v123"
-#define TA_PIN_R20 "v124"
-#elif TA_PIN_BASE == 88
-#define TA_PIN_CLOBBERS "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100", "v101", "v102", "v103", "v104", "v105", "v106", "v107", "v108"
-#define TA_PIN_Q0 "v[88:91]"
-#define TA_PIN_Q1 "v[92:95]"
-#define TA_PIN_Q2 "v[96:99]"
-#define TA_PIN_Q3 "v[100:103]"
-#define TA_PIN_Q4 "v[104:107]"
-#define TA_PIN_R0 "v88"
-#define TA_PIN_R1 "v89"
-#define TA_PIN_R2 "v90"
-#define TA_PIN_R3 "v91"
-#define TA_PIN_R4 "v92"
-#define TA_PIN_R5 "v93"
-#define TA_PIN_R6 "v94"
-#define TA_PIN_R7 "v95"
-#define TA_PIN_R8 "v96"
-#define TA_PIN_R9 "v97"
-#define TA_PIN_R10 "v98"
-#define TA_PIN_R11 "v99"
-#define TA_PIN_R12 "v100"
-#define TA_PIN_R13 "v101"
-#define TA_PIN_R14 "v102"
-#define TA_PIN_R15 "v103"
-#define TA_PIN_R16 "v104"
-#define TA_PIN_R17 "v105"
-#define TA_PIN_R18 "v106"
-#define TA_PIN_R19 "v107"
-#define TA_PIN_R20 "v108"
-#elif TA_PIN_BASE == 80
-#define TA_PIN_CLOBBERS "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99", "v100"
-#define TA_PIN_Q0 "v[80:83]"
-#define TA_PIN_Q1 "v[84:87]"
-#define TA_PIN_Q2 "v[88:91]"
-#define TA_PIN_Q3 "v[92:95]"
-#define TA_PIN_Q4 "v[96:99]"
-#define TA_PIN_R0 "v80"
-#define TA_PIN_R1 "v81"
-#define TA_PIN_R2 "v82"
-#define TA_PIN_R3 "v83"
-#define TA_PIN_R4 "v84"
-#define TA_PIN_R5 "v85"
-#define TA_PIN_R6 "v86"
-#define TA_PIN_R7 "v87"
-#define TA_PIN_R8 "v88"
-#define TA_PIN_R9 "v89"
-#define TA_PIN_R10 "v90"
-#define TA_PIN_R11 "v91"
-#define TA_PIN_R12 "v92"
-#define TA_PIN_R13 "v93"
-#define TA_PIN_R14 "v94"
-#define TA_PIN_R15 "v95"
-#define TA_PIN_R16 "v96"
-#define TA_PIN_R17 "v97"
-#define TA_PIN_R18 "v98"
-#define TA_PIN_R19 "v99"
-#define TA_PIN_R20 "v100"
-#elif TA_PIN_BASE == 75
-#define TA_PIN_CLOBBERS "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95"
-#define TA_PIN_Q0 "v[75:78]"
-#define TA_PIN_Q1 "v[79:82]"
-#define TA_PIN_Q2 "v[83:86]"
-#define TA_PIN_Q3 "v[87:90]"
-#define TA_PIN_Q4 "v[91:94]"
-#define TA_PIN_R0 "v75"
-#define TA_PIN_R1 "v76"
-#define TA_PIN_R2 "v77"
-#define TA_PIN_R3 "v78"
-#define TA_PIN_R4 "v79"
-#define TA_PIN_R5 "v80"
-#define TA_PIN_R6 "v81"
-#define TA_PIN_R7 "v82"
-#define TA_PIN_R8 "v83"
-#define TA_PIN_R9 "v84"
-#define TA_PIN_R10 "v85"
-#define TA_PIN_R11 "v86"
-#define TA_PIN_R12 "v87"
-#define TA_PIN_R13 "v88"
-#define TA_PIN_R14 "v89"
-#define TA_PIN_R15 "v90"
-#define TA_PIN_R16 "v91"
-#define TA_PIN_R17 "v92"
-#define TA_PIN_R18 "v93"
-#define TA_PIN_R19 "v94"
-#define TA_PIN_R20 "v95"
-#elif TA_PIN_BASE == 72
-#define TA_PIN_CLOBBERS "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92"
-#define TA_PIN_Q0 "v[72:75]"
-#define TA_PIN_Q1 "v[76:79]"
-#define TA_PIN_Q2 "v[80:83]"
-#define TA_PIN_Q3 "v[84:87]"
-#define TA_PIN_Q4 "v[88:91]"
-#define TA_PIN_R0 "v72"
-#define TA_PIN_R1 "v73"
-#define TA_PIN_R2 "v74"
-#define TA_PIN_R3 "v75"
-#define TA_PIN_R4 "v76"
-#define TA_PIN_R5 "v77"
-#define TA_PIN_R6 "v78"
-#define TA_PIN_R7 "v79"
-#define TA_PIN_R8 "v80"
-#define TA_PIN_R9 "v81"
-#define TA_PIN_R10 "v82"
-#define TA_PIN_R11 "v83"
-#define TA_PIN_R12 "v84"
-#define TA_PIN_R13 "v85"
-#define TA_PIN_R14 "v86"
-#define TA_PIN_R15 "v87"
-#define TA_PIN_R16 "v88"
-#define TA_PIN_R17 "v89"
-#define TA_PIN_R18 "v90"
-#define TA_PIN_R19 "v91"
-#define TA_PIN_R20 "v92"
-#elif TA_PIN_BASE == 64
-#define TA_PIN_CLOBBERS "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84"
-#define TA_PIN_Q0 "v[64:67]"
-#define TA_PIN_Q1 "v[68:71]"
-#define TA_PIN_Q2 "v[72:75]"
-#define TA_PIN_Q3 "v[76:79]"
-#define TA_PIN_Q4 "v[80:83]"
-#define TA_PIN_R0 "v64"
-#define TA_PIN_R1 "v65"
-#define TA_PIN_R2 "v66"
-#define TA_PIN_R3 "v67"
-#define TA_PIN_R4 "v68"
-#define TA_PIN_R5 "v69"
-#define TA_PIN_R6 "v70"
-#define TA_PIN_R7 "v71"
-#define TA_PIN_R8 "v72"
-#define TA_PIN_R9 "v73"
-#define TA_PIN_R10 "v74"
-#define TA_PIN_R11 "v75"
-#define TA_PIN_R12 "v76"
-#define TA_PIN_R13 "v77"
-#define TA_PIN_R14 "v78"
-#define TA_PIN_R15 "v79"
-#define TA_PIN_R16 "v80"
-#define TA_PIN_R17 "v81"
-#define TA_PIN_R18 "v82"
-#define TA_PIN_R19 "v83"
-#define TA_PIN_R20 "v84"
-#elif TA_PIN_BASE == 59
-#define TA_PIN_CLOBBERS "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79"
-#define TA_PIN_Q0 "v[59:62]"
-#define TA_PIN_Q1 "v[63:66]"
-#define TA_PIN_Q2 "v[67:70]"
-#define TA_PIN_Q3 "v[71:74]"
-#define TA_PIN_Q4 "v[75:78]"
-#define TA_PIN_R0 "v59"
-#define TA_PIN_R1 "v60"
-#define TA_PIN_R2 "v61"
-#define TA_PIN_R3 "v62"
-#define TA_PIN_R4 "v63"
-#define TA_PIN_R5 "v64"
-#define TA_PIN_R6 "v65"
-#define TA_PIN_R7 "v66"
-#define TA_PIN_R8 "v67"
-#define TA_PIN_R9 "v68"
-#define TA_PIN_R10 "v69"
-#define TA_PIN_R11 "v70"
-#define TA_PIN_R12 "v71"
-#define TA_PIN_R13 "v72"
-#define TA_PIN_R14 "v73"
-#define TA_PIN_R15 "v74"
-#define TA_PIN_R16 "v75"
-#define TA_PIN_R17 "v76"
-#define TA_PIN_R18 "v77"
-#define TA_PIN_R19 "v78"
-#define TA_PIN_R20 "v79"
-#elif TA_PIN_BASE == 56
-#define TA_PIN_CLOBBERS "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76"
-#define TA_PIN_Q0 "v[56:59]"
-#define TA_PIN_Q1 "v[60:63]"
-#define TA_PIN_Q2 "v[64:67]"
-#define TA_PIN_Q3 "v[68:71]"
-#define TA_PIN_Q4 "v[72:75]"
-#define TA_PIN_R0 "v56"
-#define TA_PIN_R1 "v57"
-#define TA_PIN_R2 "v58"
-#define TA_PIN_R3 "v59"
-#define TA_PIN_R4 "v60"
-#define TA_PIN_R5 "v61"
-#define TA_PIN_R6 "v62"
-#define TA_PIN_R7 "v63"
-#define TA_PIN_R8 "v64"
-#define TA_PIN_R9 "v65"
-#define TA_PIN_R10 "v66"
-#define TA_PIN_R11 "v67"
-#define TA_PIN_R12 "v68"
-#define TA_PIN_R13 "v69"
-#define TA_PIN_R14 "v70"
-#define TA_PIN_R15 "v71"
-#define TA_PIN_R16 "v72"
-#define TA_PIN_R17 "v73"
-#define TA_PIN_R18 "v74"
-#define TA_PIN_R19 "v75"
-#define TA_PIN_R20 "v76"
-#else
-#error "no register names written out for this TA_PIN_BASE"
-#endif
-template <int Q>      // quad Q of the pinned registers <- 16 bytes at sbase + voff
-__device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
-    if (Q == 0)      asm volatile("global_load_dwordx4 " TA_PIN_Q0 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-    else if (Q == 1) asm volatile("global_load_dwordx4 " TA_PIN_Q1 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-    else if (Q == 2) asm volatile("global_load_dwordx4 " TA_PIN_Q2 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-    else if (Q == 3) asm volatile("global_load_dwordx4 " TA_PIN_Q3 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-    else             asm volatile("global_load_dwordx4 " TA_PIN_Q4 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-}
-template <typename T, int RB>
-__device__ __forceinline__ void issue_voxel(uint32_t voff, const void* sbase) {
-    if (sizeof(T) == 4) {
-        if (RB == 4) asm volatile("global_load_dword " TA_PIN_R20 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-        else         asm volatile("global_load_dword " TA_PIN_R12 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-    } else {
-        if (RB == 4) asm volatile("global_load_ushort " TA_PIN_R20 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
-        else         asm volatile("global_load_ushort " TA_PIN_R12 ", %0, %1" :: "v"(voff), "s"(sbase) : "memory", TA_PIN_CLOBBERS);
+// (generated: the register names of the two budgets in use, written out)
+#define TA_PIN_ADJ 104        // kernels with adjacency: 104 compiler-allocated VGPRs + 21 pinned = 125: four waves per SIMD
+#define TA_PIN_MOM 76         // kernels without (rows only: no row above, no voxel to the left): 76 + 16 = 92: five waves
+// amdgpu_num_vgpr is a request the allocator overshoots when it would have to spill: ask for less than the first
+// pinned register; the build checks the generated code (tissue_analysis_amd/build.py).
+#define TA_CAP_ADJ 100
+#define TA_CAP_MOM 72
+template <int BASE> struct Pin;
+template <> struct Pin<104> {
+    template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
+        if (Q == 0) asm volatile("global_load_dwordx4 v[104:107], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
+        else if (Q == 1) asm volatile("global_load_dwordx4 v[108:111], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
+        else if (Q == 2) asm volatile("global_load_dwordx4 v[112:115], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
+        else if (Q == 3) asm volatile("global_load_dwordx4 v[116:119], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
+        else asm volatile("global_load_dwordx4 v[120:123], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
     }
-}
-// wait for every hand-issued load and move the plane into ordinary registers
-#define TA_RD(i, r) "v_mov_b32 %" #i ", " r "\n"
-template <int RB>
-__device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {
-    if (RB == 4) {
-        asm volatile("s_waitcnt vmcnt(0)\n"
-                     TA_RD(0, TA_PIN_R0) TA_RD(1, TA_PIN_R1) TA_RD(2, TA_PIN_R2) TA_RD(3, TA_PIN_R3)
-                     TA_RD(4, TA_PIN_R4) TA_RD(5, TA_PIN_R5) TA_RD(6, TA_PIN_R6) TA_RD(7, TA_PIN_R7)
-                     TA_RD(8, TA_PIN_R8) TA_RD(9, TA_PIN_R9) TA_RD(10, TA_PIN_R10) TA_RD(11, TA_PIN_R11)
-                     TA_RD(12, TA_PIN_R12) TA_RD(13, TA_PIN_R13) TA_RD(14, TA_PIN_R14) TA_RD(15, TA_PIN_R15)
-                     TA_RD(16, TA_PIN_R16) TA_RD(17, TA_PIN_R17) TA_RD(18, TA_PIN_R18) TA_RD(19, TA_PIN_R19)
-                     TA_RD(20, TA_PIN_R20)
-                     : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
-                       "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
-                       "=&v"(raw[RB > 2 ? 2 : 0].x), "=&v"(raw[RB > 2 ? 2 : 0].y), "=&v"(raw[RB > 2 ? 2 : 0].z), "=&v"(raw[RB > 2 ? 2 : 0].w),
-                       "=&v"(raw[RB > 3 ? 3 : 0].x), "=&v"(raw[RB > 3 ? 3 : 0].y), "=&v"(raw[RB > 3 ? 3 : 0].z), "=&v"(raw[RB > 3 ? 3 : 0].w),
-                       "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
-                     :: "memory");
-    } else {
-        asm volatile("s_waitcnt vmcnt(0)\n"
-                     TA_RD(0, TA_PIN_R0) TA_RD(1, TA_PIN_R1) TA_RD(2, TA_PIN_R2) TA_RD(3, TA_PIN_R3)
-                     TA_RD(4, TA_PIN_R4) TA_RD(5, TA_PIN_R5) TA_RD(6, TA_PIN_R6) TA_RD(7, TA_PIN_R7)
-                     TA_RD(8, TA_PIN_R8) TA_RD(9, TA_PIN_R9) TA_RD(10, TA_PIN_R10) TA_RD(11, TA_PIN_R11)
-                     TA_RD(12, TA_PIN_R12)
-                     : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
-                       "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
-                       "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
-                     :: "memory");
+    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t voff, const void* sbase) {
+        if (sizeof(T) == 4 && RB == 4) asm volatile("global_load_dword v124, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
+        if (sizeof(T) == 4 && RB != 4) asm volatile("global_load_dword v116, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
+        if (sizeof(T) != 4 && RB == 4) asm volatile("global_load_ushort v124, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
+        if (sizeof(T) != 4 && RB != 4) asm volatile("global_load_ushort v116, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
     }
-}
-#undef TA_RD
+    template <int RB> static __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {
+        if (RB == 4) {
+            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v104\n" "v_mov_b32 %1, v105\n" "v_mov_b32 %2, v106\n" "v_mov_b32 %3, v107\n" "v_mov_b32 %4, v108\n" "v_mov_b32 %5, v109\n" "v_mov_b32 %6, v110\n" "v_mov_b32 %7, v111\n" "v_mov_b32 %8, v112\n" "v_mov_b32 %9, v113\n" "v_mov_b32 %10, v114\n" "v_mov_b32 %11, v115\n" "v_mov_b32 %12, v116\n" "v_mov_b32 %13, v117\n" "v_mov_b32 %14, v118\n" "v_mov_b32 %15, v119\n" "v_mov_b32 %16, v120\n" "v_mov_b32 %17, v121\n" "v_mov_b32 %18, v122\n" "v_mov_b32 %19, v123\n" "v_mov_b32 %20, v124\n" 
+                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
+                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
+                           "=&v"(raw[RB > 2 ? 2 : 0].x), "=&v"(raw[RB > 2 ? 2 : 0].y), "=&v"(raw[RB > 2 ? 2 : 0].z), "=&v"(raw[RB > 2 ? 2 : 0].w),
+                           "=&v"(raw[RB > 3 ? 3 : 0].x), "=&v"(raw[RB > 3 ? 3 : 0].y), "=&v"(raw[RB > 3 ? 3 : 0].z), "=&v"(raw[RB > 3 ? 3 : 0].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
+                         :: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v104\n" "v_mov_b32 %1, v105\n" "v_mov_b32 %2, v106\n" "v_mov_b32 %3, v107\n" "v_mov_b32 %4, v108\n" "v_mov_b32 %5, v109\n" "v_mov_b32 %6, v110\n" "v_mov_b32 %7, v111\n" "v_mov_b32 %8, v112\n" "v_mov_b32 %9, v113\n" "v_mov_b32 %10, v114\n" "v_mov_b32 %11, v115\n" "v_mov_b32 %12, v116\n" 
+                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
+                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
+                         :: "memory");
+        }
+    }
+};
+template <> struct Pin<76> {
+    template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
+        if (Q == 0) asm volatile("global_load_dwordx4 v[76:79], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+        else if (Q == 1) asm volatile("global_load_dwordx4 v[80:83], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+        else if (Q == 2) asm volatile("global_load_dwordx4 v[84:87], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+        else asm volatile("global_load_dwordx4 v[88:91], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
+    }
+    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t, const void*) {}
+    template <int RB> static __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {
+        if (RB == 4) {
+            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v76\n" "v_mov_b32 %1, v77\n" "v_mov_b32 %2, v78\n" "v_mov_b32 %3, v79\n" "v_mov_b32 %4, v80\n" "v_mov_b32 %5, v81\n" "v_mov_b32 %6, v82\n" "v_mov_b32 %7, v83\n" "v_mov_b32 %8, v84\n" "v_mov_b32 %9, v85\n" "v_mov_b32 %10, v86\n" "v_mov_b32 %11, v87\n" "v_mov_b32 %12, v88\n" "v_mov_b32 %13, v89\n" "v_mov_b32 %14, v90\n" "v_mov_b32 %15, v91\n" 
+                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
+                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
+                           "=&v"(raw[RB > 2 ? 2 : 0].x), "=&v"(raw[RB > 2 ? 2 : 0].y), "=&v"(raw[RB > 2 ? 2 : 0].z), "=&v"(raw[RB > 2 ? 2 : 0].w),
+                           "=&v"(raw[RB > 3 ? 3 : 0].x), "=&v"(raw[RB > 3 ? 3 : 0].y), "=&v"(raw[RB > 3 ? 3 : 0].z), "=&v"(raw[RB > 3 ? 3 : 0].w)
+                         :: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v76\n" "v_mov_b32 %1, v77\n" "v_mov_b32 %2, v78\n" "v_mov_b32 %3, v79\n" "v_mov_b32 %4, v80\n" "v_mov_b32 %5, v81\n" "v_mov_b32 %6, v82\n" "v_mov_b32 %7, v83\n" 
+                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
+                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w)
+                         :: "memory");
+        }
+        (void)upr; (void)l;
+    }
+};
 template <typename T, int VPL>
 __device__ __forceinline__ void unpack_strip(const u32x4& x, uint32_t (&dst)[VPL]) {
     if (sizeof(T) == 4) {
@@ -566,10 +352,10 @@ __device__ __forceinline__ void unpack_strip(const u32x4& x, uint32_t (&dst)[VPL
 template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, typename LDS>
 __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* kp, LDS& S, const int lane, const int w,
                                           const uint32_t c_tile0, const uint32_t b_tile0,
-                                          const int32_t p_lo, const int32_t p_hi, const uint32_t A0) {
+                                          const int32_t p_lo, const int32_t p_hi) {
     constexpr int TC = 64 * VPL;
     static_assert(TC <= 512, "the run code holds the end column in 10 bits");
-    static_assert(FCAP >= 2 * VPL && RCAP >= VPL + 1, "the records of one lane must fit a buffer");
+    static_assert(FCAP >= RB * VPL && RCAP >= VPL + 1, "the records of one lane must fit a buffer");
     auto& W = S.wave[w];
 
     const T* vol = reinterpret_cast<const T*>(A.vol);
@@ -582,11 +368,11 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     const uint32_t lane_c = (uint32_t)lane * VPL;
     const uint32_t lane_off = lane_c * (uint32_t)sizeof(T);
 
-    uint32_t cur[RB][VPL], prv[RB][VPL], up[VPL];
+    // The working set of a lane: the RB x VPL voxels of the CURRENT plane, the strip of the row above, the voxel to
+    // the left.  The previous plane is never kept: its faces with the current one are taken at the moment the new
+    // plane lands, while both are in registers (that is what leaves room for a fifth wave per SIMD).
+    uint32_t cur[RB][VPL], up[VPL];
     uint32_t leftv = INVALID_LABEL;                        // lane r: the voxel left of row r of the tile
-    // the plane in flight: unpacked (edge tiles, compiler-managed loads) or raw strips (interior tiles, hand-issued)
-    uint32_t nxt[RB][VPL], nxt_up[VPL], nxt_leftv = INVALID_LABEL;
-    u32x4 nraw[RB], nup_raw;                               // (the plane just read back from the pinned registers)
     static_assert(RB == 2 || RB == 4, "the pinned-register layout is written out for 2 and 4 rows");
     bool bad = false;
 
@@ -613,68 +399,109 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             scan_load_strip<T, VPL>(true, row, row_ok, lane_off, c0g, n2, dup, bad);
         }
     };
-    // -- interior tiles: every load is unconditional (a tile without a row above / a column to the left reads its
-    //    own first row / column instead and never looks at the result), RB + 2 loads per plane
+    // -- interior tiles: every load is unconditional, RB + 2 loads per plane.  A tile without a row above / a column
+    //    to the left reads its own first row / column instead: those compares can never fire, so the hot loop does
+    //    not test has_up / has_left at all.  One running pointer walks the planes.
     const uint32_t rowbytes = (uint32_t)(n2 * (int64_t)sizeof(T));
     const uint32_t left_off = (uint32_t)(lane & (RB - 1)) * rowbytes;    // (the VGPR offset of a load is unsigned)
-    auto issue_plane = [&](int64_t p) {
-        const char* row0 = reinterpret_cast<const char*>(vol + p * plane + b_wave0 * n2 + c_tile0);
-        issue_strip<0>(lane_off, row0);
-        issue_strip<1>(lane_off, row0 + rowbytes);
-        if (RB > 2) { issue_strip<2>(lane_off, row0 + 2 * (int64_t)rowbytes); issue_strip<3>(lane_off, row0 + 3 * (int64_t)rowbytes); }
-        if (RB > 2) issue_strip<4>(lane_off, has_up ? row0 - rowbytes : row0);
-        else        issue_strip<2>(lane_off, has_up ? row0 - rowbytes : row0);
-        issue_voxel<T, RB>(left_off, has_left ? row0 - sizeof(T) : row0);
+    const int64_t plane_bytes = plane * (int64_t)sizeof(T);
+    const char* next_row0 = reinterpret_cast<const char*>(vol + (int64_t)(has_prev ? p_lo - 1 : p_lo) * plane + b_wave0 * n2 + c_tile0);
+    auto issue_plane = [&]() {                            // issues the plane at `next_row0` and steps it
+        const char* row0 = next_row0;
+        next_row0 += plane_bytes;
+        using P = Pin<ADJ ? TA_PIN_ADJ : TA_PIN_MOM>;
+        P::template issue_strip<0>(lane_off, row0);
+        P::template issue_strip<1>(lane_off, row0 + rowbytes);
+        if (RB > 2) { P::template issue_strip<2>(lane_off, row0 + 2 * (int64_t)rowbytes); P::template issue_strip<3>(lane_off, row0 + 3 * (int64_t)rowbytes); }
+        if (ADJ) {       // (without adjacency nobody looks at the row above or the voxel to the left)
+            if (RB > 2) P::template issue_strip<4>(lane_off, has_up ? row0 - rowbytes : row0);
+            else        P::template issue_strip<2>(lane_off, has_up ? row0 - rowbytes : row0);
+            P::template issue_voxel<T, RB>(left_off, has_left ? row0 - sizeof(T) : row0);
+        }
     };
-
-#pragma unroll
-    for (int j = 0; j < VPL; ++j) { up[j] = INVALID_LABEL; nxt_up[j] = INVALID_LABEL; }
-    if constexpr (EDGE) {
-        load_rows(p_lo, cur);
-        load_halo(p_lo, up, leftv);
-        if (has_prev) {
-            load_rows(p_lo - 1, prv);      // the plane before the tile (another tile's, or the slab's halo plane)
-        } else {
-#pragma unroll
-            for (int r = 0; r < RB; ++r)
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) prv[r][j] = cur[r][j];
-        }
-        if (p_lo + 1 < p_hi) { load_rows(p_lo + 1, nxt); load_halo(p_lo + 1, nxt_up, nxt_leftv); }
-    } else {
-        if (has_prev) {
-            issue_plane(p_lo - 1);
-            landed<RB>(nraw, nup_raw, nxt_leftv);
-#pragma unroll
-            for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], prv[r]);
-        }
-        issue_plane(p_lo);
-        landed<RB>(nraw, nup_raw, nxt_leftv);
-#pragma unroll
-        for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], cur[r]);
-        unpack_strip<T, VPL>(nup_raw, up);
-        leftv = nxt_leftv;
-        if (!has_prev) {
-#pragma unroll
-            for (int r = 0; r < RB; ++r)
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) prv[r][j] = cur[r][j];
-        }
-        if (p_lo + 1 < p_hi) issue_plane(p_lo + 1);
-    }
 
     uint32_t fcount = 0u, rcount = 0u;                    // records in the buffers (wave-uniform)
     if (lane == 0) W.cqc[0] = NO_ROW;
-    // Leading rows of the tile that are one label (the label of its first voxel) from end to end are not records:
-    // they are counted and added in closed form at the end -- that is the whole cost of background.
-    const uint32_t first_label = __builtin_amdgcn_readfirstlane(cur[0][0]);
-    bool leading = true;
-    uint32_t nlead = 0u;
     // LDS byte offsets of the wave's buffers (the low half of a flat LDS address is the LDS offset)
     const uint32_t fbase = (uint32_t)(uintptr_t)&W.frec[0];
     const uint32_t rbase = (uint32_t)(uintptr_t)&W.cqv[1];
     constexpr uint32_t RSTRIDE = (RCAP + 1) * 4u;         // bytes between the three run arrays
-    const uint32_t B0 = b_tile0, C0 = c_tile0;
+
+    // One packed add-scan over the lanes gives every lane the offset of its first record (faces in the low half of
+    // `cnt`, runs in the high half); the totals say whether the records fit.  One trip, unless they do not: then the
+    // buffers are drained first, and a set too big even for empty buffers (noise, never tissue) goes a lane range at a
+    // time.  `emit(offf, offr)` stores the lane's records at its offsets.
+    auto place_records = [&](const uint32_t cnt, auto&& emit) {
+        uint32_t lo = 0u, hi = 64u;
+        for (;;) {
+            const bool insel = ((uint32_t)lane - lo) < (hi - lo);
+            const uint32_t mine = insel ? cnt : 0u;
+            const uint32_t incl = wave_scan_add(mine);
+            const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            const uint32_t rowf = tot & 0xffffu, rowr = tot >> 16;
+            const bool fits = fcount + rowf <= (uint32_t)FCAP && rcount + rowr <= (uint32_t)RCAP;
+            if (TA_ABLATE >= 3) break;
+            if (fits) {
+                const uint32_t excl = incl - mine;
+                const uint32_t offf = fbase + ((fcount + (excl & 0xffffu)) << 3);     // LDS address of the lane's next face record
+                const uint32_t offr = rbase + ((rcount + (excl >> 16)) << 2);         // ... and of its next run record (first array)
+                fcount += rowf; rcount += rowr;
+                if (insel && TA_ABLATE < 2) emit(offf, offr);
+                lo = hi; hi = 64u;
+            } else if ((fcount | rcount) == 0u) {
+                hi = lo + ((hi - lo) >> 1);               // too big even for empty buffers: half the lanes
+                continue;
+            }
+            if (!fits || fcount >= (uint32_t)FDRAIN || rcount >= (uint32_t)RDRAIN)
+                drain_buffers<ADJ, MOM2, LDS>(kp, S, EDGE, w, lane, fcount, rcount);
+            if (lo >= 64u) break;
+        }
+    };
+    // A new plane `nw` has landed: its faces with the current plane (axis 0), while both are in registers.
+    auto plane_faces = [&](const uint32_t (&nw)[RB][VPL]) {
+        uint32_t cf = 0u;
+#pragma unroll
+        for (int r = 0; r < RB; ++r)
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) cf += (nw[r][j] != cur[r][j]) ? 1u : 0u;
+        if (__builtin_amdgcn_ballot_w64(cf != 0u) == 0ull) return;
+        place_records(cf, [&](uint32_t offf, uint32_t) {
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    uint32_t v = nw[r][j];
+                    asm volatile("" : "+v"(v));           // (compare again: see the row emission)
+                    if (v != cur[r][j]) {
+                        *(lds_u32)(uintptr_t)offf = v; *(lds_u32)(uintptr_t)(offf + 4u) = cur[r][j];
+                        offf += 8u;
+                    }
+                }
+        });
+    };
+
+    // ---- prologue: the plane before the tile (another tile's, or the slab's halo plane) only gives faces
+    uint32_t nxt[RB][VPL], nxt_up[VPL], nxt_leftv = INVALID_LABEL;           // edge tiles: the plane in flight, unpacked
+    u32x4 nraw[RB], nup_raw;                                                  // interior tiles: the plane just read back
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) { up[j] = INVALID_LABEL; nxt_up[j] = INVALID_LABEL; }
+    if constexpr (EDGE) {
+        if (has_prev) load_rows(p_lo - 1, cur);
+        load_rows(p_lo, nxt); load_halo(p_lo, nxt_up, nxt_leftv);
+    } else {
+        if (has_prev) {
+            issue_plane();
+            Pin<ADJ ? TA_PIN_ADJ : TA_PIN_MOM>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+#pragma unroll
+            for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], cur[r]);
+        }
+        issue_plane();
+    }
+    // Leading rows of the tile that are one label (the label of its first voxel) from end to end are not records:
+    // they are counted and added in closed form at the end -- that is the whole cost of background.
+    uint32_t first_label = INVALID_LABEL;
+    bool leading = true;
+    uint32_t nlead = 0u;
 
 #ifdef TA_STAMPS
     uint64_t tk_cmp = 0, tk_emit = 0, tk_drain = 0, tk_adv = 0, tk_rows = 0, tk_evrows = 0, tk_drains = 0;
@@ -683,6 +510,38 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #endif
     for (int32_t p = p_lo; p < p_hi; ++p) {
         const uint32_t ploc = (uint32_t)(p - p_lo);
+        // ---- the plane in flight lands (it was issued a whole plane of compute ago); the next one is issued
+#ifdef TA_STAMPS
+        const uint64_t t4 = TA_T();
+#endif
+        if constexpr (EDGE) {
+            if (ADJ && (p > p_lo || has_prev)) plane_faces(nxt);
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) cur[r][j] = nxt[r][j];
+            leftv = nxt_leftv;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) up[j] = nxt_up[j];
+            if (p + 1 < p_hi) { load_rows(p + 1, nxt); load_halo(p + 1, nxt_up, nxt_leftv); }
+        } else {
+            Pin<ADJ ? TA_PIN_ADJ : TA_PIN_MOM>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+            if (p + 1 < p_hi) issue_plane();
+            uint32_t nw[RB][VPL];
+#pragma unroll
+            for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], nw[r]);
+            if (ADJ && (p > p_lo || has_prev)) plane_faces(nw);
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) cur[r][j] = nw[r][j];
+            if (ADJ) unpack_strip<T, VPL>(nup_raw, up);
+            leftv = nxt_leftv;
+        }
+        if (p == p_lo) first_label = __builtin_amdgcn_readfirstlane(cur[0][0]);
+#ifdef TA_STAMPS
+        tk_adv += TA_T() - t4;
+#endif
 #pragma unroll
         for (int r = 0; r < RB; ++r) {
             const uint32_t bloc = (uint32_t)(w * RB + r);
@@ -697,15 +556,12 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             for (int j = 0; j < VPL; ++j) {
                 const uint32_t v = cur[r][j];
                 if (j > 0) pcv[j] = cur[r][j > 0 ? j - 1 : 0];
-                else pcv[j] = lane_shr1(cur[r][VPL - 1], has_left ? (uint32_t)__builtin_amdgcn_readlane((int)leftv, r) : cur[r][0]);
+                else pcv[j] = lane_shr1(cur[r][VPL - 1], (ADJ && (!EDGE || has_left)) ? (uint32_t)__builtin_amdgcn_readlane((int)leftv, r) : cur[r][0]);
                 const bool fc = v != pcv[j];
                 cr += fc ? 1u : 0u;
                 const uint64_t mc = __builtin_amdgcn_ballot_w64(fc);
                 inner |= j == 0 ? (mc & ~1ull) : mc;
-                if (ADJ) {
-                    if (r > 0 || has_up) cf += (v != (r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j])) ? 1u : 0u;
-                    cf += (v != prv[r][j]) ? 1u : 0u;
-                }
+                if (ADJ && (r > 0 || !EDGE || has_up)) cf += (v != (r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j])) ? 1u : 0u;
             }
             const uint32_t rowlab = __builtin_amdgcn_readfirstlane(cur[r][0]);
             const bool uniform = inner == 0ull;
@@ -724,119 +580,43 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #else
             if (__builtin_amdgcn_ballot_w64(cnt != 0u) == 0ull) continue;       // the common case: one branch per row
 #endif
-
-            // ---- 2. one packed add-scan over the lanes gives every lane the offset of its first record; the totals
-            //         say whether the row fits.  One trip, unless the row does not fit: then the buffers are drained
-            //         first, and a row too big even for empty buffers (noise, never tissue) goes a lane range at a time.
-            uint32_t lo = 0u, hi = 64u;
-            for (;;) {
-                // (laundered: keeps the tagged / coded copies of the row's registers from being hoisted out of this
-                //  loop into long-lived registers)
+            // ---- 2. + 3. offsets, then a firing lane stores at its own offset and steps it
+            place_records(cnt, [&](uint32_t offf, uint32_t offr) {
+                // (laundered: keeps the tagged / coded copies of the row's registers out of long-lived registers)
                 uint32_t tag1 = 1u << 30;
                 uint32_t rowcode = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bloc << 10) | (ploc << 14)));
                 if (ADJ) asm volatile("" : "+s"(tag1));
                 asm volatile("" : "+s"(rowcode));
-                const bool insel = ((uint32_t)lane - lo) < (hi - lo);
-                const uint32_t mine = insel ? cnt : 0u;
-                const uint32_t incl = wave_scan_add(mine);
-                const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-                const uint32_t rowf = tot & 0xffffu, rowr = tot >> 16;
-                const bool fits = fcount + rowf <= (uint32_t)FCAP && rcount + rowr <= (uint32_t)RCAP;
-                if (TA_ABLATE >= 3) break;
-                if (fits) {
-                    const uint32_t excl = incl - mine;
-                    uint32_t offf = fbase + ((fcount + (excl & 0xffffu)) << 3);     // LDS address of the lane's next face record
-                    uint32_t offr = rbase + ((rcount + (excl >> 16)) << 2);         // ... and of its next run record (first array)
-                    fcount += rowf; rcount += rowr;
-                    if (insel && TA_ABLATE < 2) {
-                        // ---- 3. emit: a firing lane stores at its own offset and steps it
 #pragma unroll
-                        for (int j = 0; j < VPL; ++j) {
-                            const uint32_t v = cur[r][j];
-                            if (ADJ) {
-                                if (r > 0 || has_up) {
-                                    const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];
-                                    if (v != pv) {
-                                        *(lds_u32)(uintptr_t)offf = v; *(lds_u32)(uintptr_t)(offf + 4u) = pv | tag1;
-                                        offf += 8u;
-                                    }
-                                }
-                                {
-                                    const uint32_t pv = prv[r][j];
-                                    if (v != pv) {
-                                        *(lds_u32)(uintptr_t)offf = v; *(lds_u32)(uintptr_t)(offf + 4u) = pv;
-                                        offf += 8u;
-                                    }
-                                }
-                            }
-                            if (v != pcv[j]) {
-                                if (ADJ) *(lds_u32)(uintptr_t)offr = v;
-                                *(lds_u32)(uintptr_t)(offr + RSTRIDE) = pcv[j];
-                                *(lds_u32)(uintptr_t)(offr + 2u * RSTRIDE) = (lane_c + (uint32_t)j) | rowcode;
-                                offr += 4u;
-                            }
-                        }
-                        if (need_end && lane == 63) {
-                            if (ADJ) *(lds_u32)(uintptr_t)offr = INVALID_LABEL;
-                            *(lds_u32)(uintptr_t)(offr + RSTRIDE) = cur[r][VPL - 1];
-                            *(lds_u32)(uintptr_t)(offr + 2u * RSTRIDE) = (uint32_t)TC | rowcode;
+                for (int j = 0; j < VPL; ++j) {
+                    // (an opaque copy: the compares are done again here instead of keeping a dozen 64-bit lane masks
+                    //  alive from the counting pass across the scan -- and across a drain -- in scarce SGPRs)
+                    uint32_t v = cur[r][j];
+                    asm volatile("" : "+v"(v));
+                    if (ADJ && (r > 0 || !EDGE || has_up)) {
+                        const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];
+                        if (v != pv) {
+                            *(lds_u32)(uintptr_t)offf = v; *(lds_u32)(uintptr_t)(offf + 4u) = pv | tag1;
+                            offf += 8u;
                         }
                     }
-                    lo = hi; hi = 64u;
-                } else if ((fcount | rcount) == 0u) {
-                    hi = lo + ((hi - lo) >> 1);           // too big even for empty buffers: half the lanes
-                    continue;
-                }
-#ifdef TA_STAMPS
-                const uint64_t t2 = TA_T();
-                tk_emit += t2 - t1;
-#endif
-                if (!fits || fcount >= (uint32_t)FDRAIN || rcount >= (uint32_t)RDRAIN) {
-                    drain_buffers<ADJ, MOM2, LDS>(kp, S, A0, B0, C0, EDGE, w, lane, fcount, rcount);
-#ifdef TA_STAMPS
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    tk_drain += TA_T() - t2; tk_drains += 1;
-#endif
-                }
-                if (lo >= 64u) break;
-            }
-        }
-        // ---- advance: the plane in flight becomes the current one, the next one is issued
-#ifdef TA_STAMPS
-        const uint64_t t4 = TA_T();
-#endif
-        if (p + 1 < p_hi) {
-            if constexpr (EDGE) {
-#pragma unroll
-                for (int r = 0; r < RB; ++r) {
-#pragma unroll
-                    for (int j = 0; j < VPL; ++j) {
-                        if (ADJ) prv[r][j] = cur[r][j];
-                        cur[r][j] = nxt[r][j];
+                    if (v != pcv[j]) {
+                        if (ADJ) *(lds_u32)(uintptr_t)offr = v;
+                        *(lds_u32)(uintptr_t)(offr + RSTRIDE) = pcv[j];
+                        *(lds_u32)(uintptr_t)(offr + 2u * RSTRIDE) = (lane_c + (uint32_t)j) | rowcode;
+                        offr += 4u;
                     }
                 }
-                leftv = nxt_leftv;
-#pragma unroll
-                for (int j = 0; j < VPL; ++j) up[j] = nxt_up[j];
-                if (p + 2 < p_hi) { load_rows(p + 2, nxt); load_halo(p + 2, nxt_up, nxt_leftv); }
-            } else {
-                landed<RB>(nraw, nup_raw, nxt_leftv);                    // issued a whole plane of compute ago
-#pragma unroll
-                for (int r = 0; r < RB; ++r) {
-                    if (ADJ) {
-#pragma unroll
-                        for (int j = 0; j < VPL; ++j) prv[r][j] = cur[r][j];
-                    }
-                    unpack_strip<T, VPL>(nraw[r], cur[r]);
+                if (need_end && lane == 63) {
+                    if (ADJ) *(lds_u32)(uintptr_t)offr = INVALID_LABEL;
+                    *(lds_u32)(uintptr_t)(offr + RSTRIDE) = cur[r][VPL - 1];
+                    *(lds_u32)(uintptr_t)(offr + 2u * RSTRIDE) = (uint32_t)TC | rowcode;
                 }
-                if (ADJ) unpack_strip<T, VPL>(nup_raw, up);
-                leftv = nxt_leftv;
-                if (p + 2 < p_hi) issue_plane(p + 2);
-            }
-        }
+            });
 #ifdef TA_STAMPS
-        tk_adv += TA_T() - t4;
+            tk_emit += TA_T() - t1;
 #endif
+        }
     }
 #ifdef TA_STAMPS
     if (lane == 0) {
@@ -849,7 +629,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #endif
 
     // ---- end of tile: drain the buffers, then the leading one-label rows in one closed form
-    drain_buffers<ADJ, MOM2, LDS>(kp, S, A0, B0, C0, EDGE, w, lane, fcount, rcount);
+    drain_buffers<ADJ, MOM2, LDS>(kp, S, EDGE, w, lane, fcount, rcount);
     if (__builtin_amdgcn_ballot_w64(bad)) { if (lane == 0) atomicOr(&cold_args(kp)->flags[FLAG_RANGE], 1u); }
     if (lane == 0 && nlead != 0u && first_label != INVALID_LABEL) {
         // rows in (plane, row) order: P full planes of RB rows, then R rows of plane P
@@ -871,7 +651,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         }
         const uint32_t mxa = (uint32_t)(R ? P : P - 1u);
         const uint32_t mxb = (uint32_t)(b0 + (P ? RB : R) - 1u);
-        scan_label_add<MOM2, LDS, LocalSums>(kp, S, A0, B0, C0, first_label, L, 0u, mxa, (uint32_t)b0, mxb, 0u,
+        scan_label_add<MOM2, LDS, LocalSums>(kp, S, first_label, L, 0u, mxa, (uint32_t)b0, mxb, 0u,
                                              (uint32_t)(nc - 1));
     }
 }
@@ -896,11 +676,11 @@ static ScanSplit scan_split(const SweepArgs& a, int itemsize) {
 }
 
 template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE>
-__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_PIN_BASE))) scan_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+__device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanSplit& sp, const uint32_t wg0) {
     constexpr int NW = MOM2 ? 6 : 2;
     constexpr int TC = 64 * VPL, TB = WAVES * RB;
     static_assert(TB <= 16 && TC <= 512, "packed LDS moment words assume <= 16 rows x 512 columns per tile");
-    using LDS = ScanLds<NW>;
+    using LDS = ScanLds<NW, ADJ>;
     __shared__ LDS S;
     // the arguments only the cold paths need are re-read from the kernarg segment there (see cold_args)
     const SweepArgs* kp = kernarg_args(A);
@@ -922,7 +702,6 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_
     }
     const uint32_t wg = wg0 + blockIdx.x;
     if (!ADJ) hot_row_init(A, tid, wg);
-    __syncthreads();
 
     uint32_t t = blockIdx.x, tc, tb, band;
     if (!EDGE) {
@@ -938,13 +717,28 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_
     int32_t p_hi = p_lo + A.tile_planes;
     if (p_hi > (int32_t)A.n0) p_hi = (int32_t)A.n0;
     const uint64_t A0 = (uint64_t)(A.a_origin + (p_lo - A.first_owned));
+    if (tid == 0) { S.frame[0] = (uint32_t)A0; S.frame[1] = b_tile0; S.frame[2] = c_tile0; }
+    __syncthreads();
 
     if (p_lo < p_hi)
-        wave_scan<T, VPL, RB, ADJ, MOM2, EDGE>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi, (uint32_t)A0);
+        wave_scan<T, VPL, RB, ADJ, MOM2, EDGE>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
     __syncthreads();
+    // (everything the flush needs is re-read -- arguments from the kernarg segment, the tile origin from LDS --
+    //  rather than kept in scarce SGPRs across the sweep)
     const SweepArgs& Ac = *cold_args(kp);
-    flush_tables<NW, ADJ, MOM2, !ADJ>(Ac, S, tid, A0, (uint64_t)b_tile0, (uint64_t)c_tile0,
-                                      ADJ ? 0u : hot_label_of<T>(Ac), wg);
+    const uint32_t wg_ = reinterpret_cast<const uint32_t*>(&Ac + 1)[sizeof(ScanSplit) / 4] + blockIdx.x;     // wg0 + block
+    flush_tables<NW, ADJ, MOM2, !ADJ>(Ac, S, threadIdx.x, (uint64_t)S.frame[0], (uint64_t)S.frame[1], (uint64_t)S.frame[2],
+                                      ADJ ? 0u : hot_label_of<T>(Ac), wg_);
+}
+
+// (two entry points only because the VGPR budget is an attribute and must be a literal)
+template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ))) scan_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+    scan_kernel_body<T, VPL, RB, true, MOM2, EDGE>(A, sp, wg0);
+}
+template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_MOM))) scan_noadj_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+    scan_kernel_body<T, VPL, RB, false, MOM2, EDGE>(A, sp, wg0);
 }
 
 template <typename T, int VPL, int RB, bool ADJ, bool MOM2>
@@ -954,8 +748,13 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a) {
     const uint32_t n_in = sp.fc * sp.fb * sp.nbands;
     const uint32_t n_ed = (sp.tiles_c * sp.tiles_b - sp.fc * sp.fb) * sp.nbands;
     const dim3 block(WAVES * 64);
-    if (n_in) hipLaunchKernelGGL((scan_kernel<T, VPL, RB, ADJ, MOM2, false>), dim3(n_in), block, 0, s, a, sp, 0u);
-    if (n_ed) hipLaunchKernelGGL((scan_kernel<T, VPL, RB, ADJ, MOM2, true>), dim3(n_ed), block, 0, s, a, sp, n_in);
+    if (ADJ) {
+        if (n_in) hipLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, a, sp, 0u);
+        if (n_ed) hipLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, a, sp, n_in);
+    } else {
+        if (n_in) hipLaunchKernelGGL((scan_noadj_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, a, sp, 0u);
+        if (n_ed) hipLaunchKernelGGL((scan_noadj_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, a, sp, n_in);
+    }
 }
 
 template <typename T, int VPL, int RB>
