@@ -73,7 +73,10 @@ TA_API int         ta_device_count(int* count);
  * volume (when uploaded with ta_volume_set), accumulators, the adjacency hash and timing events. */
 TA_API int ta_ctx_create(int device_id, ta_ctx** out);
 TA_API int ta_ctx_destroy(ta_ctx* ctx);
-TA_API int ta_ctx_set_stream(ta_ctx* ctx, void* hip_stream /* hipStream_t, caller-owned; NULL = own stream */);
+/* hip_stream: a caller-owned hipStream_t; NULL = a private non-blocking stream owned by the context (the default);
+ * TA_STREAM_LEGACY_DEFAULT = the device's legacy default ("null") stream, e.g. torch's default stream. */
+#define TA_STREAM_LEGACY_DEFAULT ((void*)1)
+TA_API int ta_ctx_set_stream(ta_ctx* ctx, void* hip_stream);
 TA_API int ta_ctx_set_option(ta_ctx* ctx, int key, int64_t value);
 /* Current effective value of an option (TA_OPT_PAIR_SLOTS: log2 of the table in use, which may
  * have grown past the requested size). */
@@ -136,6 +139,10 @@ TA_API int ta_debug_counters(ta_ctx* ctx, uint32_t out[16]);
  * whatever the buffers hold at call time, i.e. the reduced values after an all-reduce. */
 TA_API int ta_bind_accumulators(ta_ctx* ctx, void* sums_dev, void* boxes_dev, uint32_t max_label);
 TA_API int ta_accumulators_device(ta_ctx* ctx, void** sums_dev, void** boxes_dev, uint32_t* max_label);
+/* Tell the context that the bound accumulators have been reduced across ranks since the last ta_extract: a later
+ * adjacency-table overflow then returns TA_ECAPACITY (with the table already grown) instead of silently re-running
+ * the sweep on this rank alone, which would replace the global rows by local ones. */
+TA_API int ta_accumulators_reduced(ta_ctx* ctx);
 
 /* Unsorted unique pairs of the last extraction, on the device:
  * keys uint64[n] = lo<<32|hi, faces uint64[n][3] (memory-axis order). */
@@ -162,6 +169,12 @@ TA_API int ta_volume_relabel(ta_ctx* ctx, const uint32_t* lut, uint32_t lut_len)
 TA_API int ta_volume_get(ta_ctx* ctx, void* host_dst);
 TA_API int ta_volume_map(ta_ctx* ctx, const void* lut, uint32_t lut_len, const void* fill, int out_itemsize,
                          void* host_dst);
+
+/* ---- first voxel layer (voxel_first_layer, SIA:1024-1046) -------------------------
+ * out[p] = V[p] when V[p] != background and one of the six face neighbours of p is background; 1 (keep_background)
+ * or 0 where V[p] == background; 0 elsewhere -- `image * (dilate6(mask) - mask) + mask` in one stencil pass.  The host
+ * image has the dtype and dense layout of the volume given to ta_volume_set.  Not available on a slab with a halo. */
+TA_API int ta_volume_first_layer(ta_ctx* ctx, uint32_t background, int keep_background, void* host_dst);
 
 /* ---- wall voxels ------------------------------------------------------------
  * A voxel p of label l is a wall voxel of the pair (l, m) when one of its 18 neighbours (faces and

@@ -470,12 +470,40 @@ class OracleSIA(object):
                     (x + dil[0].start, y + dil[1].start, z + dil[2].start))
         return coord
 
+    def voxel_first_layer(self, keep_background=True):  # SIA:1024-1046, as written (scipy, 6-neighbourhood)
+        if getattr(self, "_voxel_layer1", None) is None:
+            img = np.asarray(self.image)
+            mask_img_1 = img == self._background
+            struct = nd.generate_binary_structure(3, 1)
+            dil_1 = nd.binary_dilation(mask_img_1, structure=struct)
+            layer = dil_1 ^ mask_img_1                  # `dil_1 - mask_img_1` of two boolean arrays (old numpy)
+            out = img * layer + mask_img_1 if keep_background else img * layer
+            self._voxel_layer1 = out.astype(img.dtype)
+        return self._voxel_layer1
+
+    def surface_area(self, labels=None, real=True):
+        """Per-label total surface (SURVEY.md §8 Semantics, last bullet): the sum of the label's wall areas with every
+        face neighbour, as the reference computes them one wall at a time (cell_wall_area, SIA:908-959); faces on the
+        border of the image belong to no wall and are not counted."""
+        single = isinstance(labels, (int, np.integer))
+        req = [int(labels)] if single else self.label_request(labels)
+        out = []
+        for l in req:
+            nei = [int(n) for n in self._shell_neighbors(l)]
+            areas = self.cell_wall_area(l, nei, real) if nei else {}
+            if not isinstance(areas, dict):
+                areas = {(min(l, nei[0]), max(l, nei[0])): areas}
+            out.append(float(sum(areas.values())))
+        return out[0] if single else self.convert_return(out, req)
+
     def wall_voxels_per_cells_pairs(self, labels=None, neighborhood=None, ignore_background=False,
-                                    min_contact_area=None, real_area=True):  # SIA:1049-1111
+                                    min_contact_area=None, real_area=True, only_epidermis=False):  # SIA:1049-1111
         compute = neighborhood is None
         if isinstance(labels, list) and isinstance(neighborhood, dict):
             labels = [l for l in labels if l in neighborhood]
-        if labels is None:
+        if labels is None and only_epidermis:           # SIA:1062-1065, 1075-1076: only the default label list changes
+            labels = [int(v) for v in np.unique(self.voxel_first_layer(True))]
+        elif labels is None:
             labels = self.labels()
         elif isinstance(labels, list):
             labels.sort()
@@ -527,6 +555,22 @@ class OracleSIA(object):
 
     def remove_stack_margin_labels_from_image(self, erase_value=0, voxel_distance_from_margin=5, verbose=False):
         self.remove_labels_from_image(self.labels_at_stack_margins(voxel_distance_from_margin), erase_value, verbose)
+
+
+def find_wall_median_voxel(array):
+    """Index of the exact medoid of a point set: what PlantGL's `pointset_median` computes for the reference's
+    `_find_wall_median_voxel` (SIA:1555-1585, <= 100 points; docstring example -> 2).  Plain double loop."""
+    a = np.asarray(array, dtype=np.float64)
+    if a.shape[0] == 3:
+        a = a.T
+    best, best_sum = 0, np.inf
+    for i in range(a.shape[0]):
+        tot = 0.0
+        for j in range(a.shape[0]):
+            tot += float(np.sqrt(((a[i] - a[j]) ** 2).sum()))
+        if tot < best_sum:
+            best, best_sum = i, tot
+    return best
 
 
 def property_image(image, property_dict, background, dtype=np.uint16):

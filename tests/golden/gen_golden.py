@@ -93,6 +93,42 @@ def adversarial():
     print("adversarial: %d cases" % len(cases))
 
 
+def docstring_case():
+    """SURVEY.md §8(c) golden item (1): the 4x6 image of the reference's docstrings with the answers the docstrings
+    give (spatial_image_analysis.py:344-353, 437-450, 498-511, 561-574, 970-982, 1219-1226), typed in by hand; the
+    oracle must reproduce every one of them before the file is written."""
+    import json
+    image = [[1, 2, 7, 7, 1, 1], [1, 6, 5, 7, 3, 3], [2, 2, 1, 7, 3, 3], [1, 1, 1, 4, 1, 1]]
+    gold = dict(
+        image=image, labels=[1, 2, 3, 4, 5, 6, 7],
+        volume={"1": 10.0, "2": 3.0, "3": 4.0, "4": 1.0, "5": 1.0, "6": 1.0, "7": 4.0},
+        center_of_mass={"1": [1.8, 2.2999999999999998, 0.0], "2": [1.3333333333333333, 0.66666666666666663, 0.0],
+                        "3": [1.5, 4.5, 0.0], "4": [3.0, 3.0, 0.0], "5": [1.0, 2.0, 0.0], "6": [1.0, 1.0, 0.0],
+                        "7": [0.75, 2.75, 0.0]},
+        boundingbox={"1": [[0, 4], [0, 6], [0, 1]], "2": [[0, 3], [0, 2], [0, 1]], "3": [[1, 3], [4, 6], [0, 1]],
+                     "4": [[3, 4], [3, 4], [0, 1]], "5": [[1, 2], [2, 3], [0, 1]], "6": [[1, 2], [1, 2], [0, 1]],
+                     "7": [[0, 3], [2, 4], [0, 1]]},
+        neighbors={"1": [2, 3, 4, 5, 6, 7], "2": [1, 6, 7], "3": [1, 7], "4": [1, 7], "5": [1, 6, 7], "6": [1, 2, 5],
+                   "7": [1, 2, 3, 4, 5]},
+        wall_areas={"1,2": 5.0, "1,3": 4.0, "1,4": 2.0, "1,5": 1.0, "1,6": 1.0, "1,7": 2.0, "2,6": 2.0, "2,7": 1.0,
+                    "3,7": 2.0, "4,7": 1.0, "5,6": 1.0, "5,7": 2.0},
+        wall_median_example=dict(points=[[0, 0, 0], [0, 1, 0], [0, 2, 0], [0, 3, 0], [0, 4, 0]], index=2),
+    )
+    sia = OracleSIA(np.array(image, dtype=np.uint16))
+    assert sia.labels() == gold["labels"]
+    vol, com, bb, nb = sia.volume(), sia.center_of_mass(), sia.boundingbox(), sia.neighbors()
+    for l in gold["labels"]:
+        assert vol[l] == gold["volume"][str(l)]
+        assert np.allclose(com[l], gold["center_of_mass"][str(l)], rtol=1e-15)
+        assert [[s.start, s.stop] for s in bb[l]] == gold["boundingbox"][str(l)]
+        assert sorted(int(v) for v in nb[l]) == gold["neighbors"][str(l)]
+    assert dict(("%d,%d" % k, float(v)) for k, v in sia.wall_areas().items()) == gold["wall_areas"]
+    with open(os.path.join(HERE, "docstring_4x6.json"), "w") as f:
+        json.dump(gold, f, indent=1, sort_keys=True)
+    print("docstring_4x6.json written")
+
+
 if __name__ == "__main__":
     config1()
     adversarial()
+    docstring_case()

@@ -73,8 +73,8 @@ def test_per_cell_and_per_pairs_methods():
         same_dict(got, want)
         assert any(k[0] == 1 for k in want) != ignore_bg or not any(1 in neigh[l] for l in some)
     same_dict(sia.wall_voxels_per_cells_pairs(verbose=False), ref.wall_voxels_per_cells_pairs())
-    with pytest.raises(NotImplementedError):
-        sia.wall_voxels_per_cells_pairs(only_epidermis=True)
+    same_dict(sia.wall_voxels_per_cells_pairs(only_epidermis=True, verbose=False),
+              ref.wall_voxels_per_cells_pairs(only_epidermis=True))
 
 
 def test_table_properties_on_a_larger_volume():

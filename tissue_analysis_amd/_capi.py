@@ -19,16 +19,17 @@ F_ALL = 31
 FEATURES = dict(VOLUME=F_VOLUME, BBOX=F_BBOX, MOMENT1=F_MOMENT1, MOMENT2=F_MOMENT2,
                 ADJACENCY=F_ADJACENCY)
 OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS = 1, 2, 3
+STREAM_LEGACY_DEFAULT = 1          # TA_STREAM_LEGACY_DEFAULT of include/tissue_scan.h
 
 # every symbol include/tissue_scan.h declares
 SYMBOLS = (
     "ta_version", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_get_option", "ta_ctx_synchronize", "ta_volume_set",
     "ta_volume_set_device", "ta_volume_max_label", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
-    "ta_wall_voxels_count", "ta_wall_voxels_get",
+    "ta_volume_first_layer", "ta_wall_voxels_count", "ta_wall_voxels_get",
     "ta_extract", "ta_get_labels",
     "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_debug_counters", "ta_bind_accumulators",
-    "ta_accumulators_device", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge",
+    "ta_accumulators_device", "ta_accumulators_reduced", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge",
     "ta_adjacency_pack", "ta_adjacency_merge_blocks", "ta_synth_voronoi",
     "ta_device_malloc", "ta_device_free", "ta_memcpy_d2h", "ta_memcpy_h2d",
 )
@@ -77,6 +78,7 @@ def load():
         "ta_volume_relabel": (ci, [vp, vp, u32]),
         "ta_volume_get": (ci, [vp, vp]),
         "ta_volume_map": (ci, [vp, vp, u32, vp, ci, vp]),
+        "ta_volume_first_layer": (ci, [vp, u32, ci, vp]),
         "ta_wall_voxels_count": (ci, [vp, P(i64)]),
         "ta_wall_voxels_get": (ci, [vp, vp, vp, vp, P(ctypes.c_double)]),
         "ta_extract": (ci, [vp, u32, u32]),
@@ -87,6 +89,7 @@ def load():
         "ta_debug_counters": (ci, [vp, P(u32)]),
         "ta_bind_accumulators": (ci, [vp, vp, vp, u32]),
         "ta_accumulators_device": (ci, [vp, P(vp), P(vp), P(u32)]),
+        "ta_accumulators_reduced": (ci, [vp]),
         "ta_adjacency_device": (ci, [vp, P(vp), P(vp), P(i64)]),
         "ta_adjacency_export": (ci, [vp, vp, vp, i64]),
         "ta_adjacency_merge": (ci, [vp, vp, vp, i64]),
@@ -172,7 +175,15 @@ class Context(object):
 
     # -- plumbing
     def set_stream(self, stream_handle):
-        _check(self._lib.ta_ctx_set_stream(self._h, ctypes.c_void_p(int(stream_handle) if stream_handle else 0)))
+        """stream_handle: a hipStream_t as an integer; 0 = the device's legacy default (null) stream -- what
+        torch.cuda.default_stream().cuda_stream is; None = a private non-blocking stream owned by the context."""
+        if stream_handle is None:
+            h = 0
+        elif int(stream_handle) == 0:
+            h = STREAM_LEGACY_DEFAULT
+        else:
+            h = int(stream_handle)
+        _check(self._lib.ta_ctx_set_stream(self._h, ctypes.c_void_p(h)))
 
     def set_option(self, key, value):
         _check(self._lib.ta_ctx_set_option(self._h, int(key), int(value)))
@@ -224,6 +235,16 @@ class Context(object):
         _check(self._lib.ta_volume_map(self._h, ctypes.c_void_p(lut.ctypes.data), int(lut.size),
                                        ctypes.c_void_p(fillv.ctypes.data), int(lut.dtype.itemsize),
                                        ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+    def first_layer(self, background, keep_background, like):
+        """voxel_first_layer of the resident volume (SIA:1024-1046) as a host image shaped and laid out like `like`
+        (the array given to set_volume)."""
+        out = np.empty_like(like)
+        if not _dense_permuted(out):
+            raise ValueError("first_layer needs a dense (possibly axis-permuted) volume")
+        _check(self._lib.ta_volume_first_layer(self._h, int(background), int(bool(keep_background)),
+                                               ctypes.c_void_p(out.ctypes.data)))
         return out
 
     def wall_voxels(self):
@@ -302,6 +323,10 @@ class Context(object):
                                               ctypes.c_void_p(int(boxes_ptr) if boxes_ptr else 0),
                                               int(max_label)))
         self._keep_acc = keep
+
+    def accumulators_reduced(self):
+        """The bound accumulators now hold other ranks' contributions (see include/tissue_scan.h)."""
+        _check(self._lib.ta_accumulators_reduced(self._h))
 
     def adjacency_device(self):
         k, f, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_int64(0)

@@ -386,6 +386,70 @@ static void launch_map_t(hipStream_t s, const void* vol, void* out, int out_item
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// First voxel layer (SIA:1024-1046): a voxel that is not background and has a background voxel among
+// its six face neighbours keeps its label, every other tissue voxel becomes 0, background becomes 1
+// (keep_background) or 0 -- `image * (dilate6(image == bg) - (image == bg)) + (image == bg)`, one stencil pass.
+// One lane = VEC consecutive voxels of a row (16 bytes): the row itself plus the four neighbouring rows come as
+// 16-byte loads (L1/L2 hits for all but one of them), the two voxels across the strip's ends as scalars.
+template <typename T>
+__global__ void __launch_bounds__(256) first_layer_kernel(const T* __restrict__ vol, T* __restrict__ out, int64_t n0,
+                                                          int64_t n1, int64_t n2, uint32_t bg, int keep_bg) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int64_t strips = (n2 + VEC - 1) / VEC, total = n0 * n1 * strips;
+    const bool vec_ok = (n2 % VEC) == 0 && ((reinterpret_cast<uintptr_t>(vol) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % strips, row = i / strips, b = row % n1, a = row / n1, c0 = s * VEC;
+        const T* r = vol + row * n2;
+        T v[VEC], up[VEC], dn[VEC], pv[VEC], nx[VEC];
+        auto load = [&](const T* rp, bool ok, T (&d)[VEC]) {
+            if (!ok) {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) d[j] = (T)0;
+            } else if (vec_ok) {
+                *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(rp + c0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) d[j] = c0 + j < n2 ? rp[c0 + j] : (T)0;
+            }
+        };
+        load(r, true, v);
+        load(r - n2, b > 0, up); load(r + n2, b + 1 < n1, dn);
+        load(r - n1 * n2, a > 0, pv); load(r + n1 * n2, a + 1 < n0, nx);
+        const bool lb = c0 > 0 && (uint32_t)r[c0 - 1] == bg, rb = c0 + VEC < n2 && (uint32_t)r[c0 + VEC] == bg;
+        T o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const bool self_bg = (uint32_t)v[j] == bg;
+            bool near = (b > 0 && (uint32_t)up[j] == bg) || (b + 1 < n1 && (uint32_t)dn[j] == bg) ||
+                        (a > 0 && (uint32_t)pv[j] == bg) || (a + 1 < n0 && (uint32_t)nx[j] == bg);
+            near = near || (j > 0 ? (uint32_t)v[j > 0 ? j - 1 : 0] == bg : lb);
+            near = near || (j + 1 < VEC ? (c0 + j + 1 < n2 && (uint32_t)v[j + 1 < VEC ? j + 1 : 0] == bg) : rb);
+            o[j] = self_bg ? (T)(keep_bg ? 1 : 0) : (near ? v[j] : (T)0);
+        }
+        if (vec_ok) {
+            *reinterpret_cast<uint4*>(out + row * n2 + c0) = *reinterpret_cast<const uint4*>(o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) if (c0 + j < n2) out[row * n2 + c0 + j] = o[j];
+        }
+    }
+}
+
+void launch_first_layer(hipStream_t s, const void* vol, int itemsize, void* out, int64_t n0, int64_t n1, int64_t n2,
+                        uint32_t background, int keep_background) {
+    const int64_t strips = (n2 + 16 / itemsize - 1) / (16 / itemsize), total = n0 * n1 * strips;
+    if (total <= 0) return;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (itemsize == 2)
+        hipLaunchKernelGGL(first_layer_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)vol,
+                           (uint16_t*)out, n0, n1, n2, background, keep_background);
+    else
+        hipLaunchKernelGGL(first_layer_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t*)vol,
+                           (uint32_t*)out, n0, n1, n2, background, keep_background);
+}
+
 void launch_map(hipStream_t s, const void* vol, int itemsize, void* out, int out_itemsize, uint64_t n,
                 const void* lut, uint32_t lut_len, uint64_t fill) {
     if (n == 0) return;

@@ -92,6 +92,7 @@ struct ta_ctx {
     uint32_t feature_mask = 0;
     bool extracted = false, checked = false;
     bool exchanged = false;                             // adjacency rebuilt by ta_adjacency_merge_blocks
+    bool reduced = false;                               // the bound accumulators hold other ranks' contributions too
     int64_t npairs = 0;
     std::vector<uint64_t> h_keys, h_faces;              // sorted host copy for ta_adjacency_get
     bool host_pairs_ready = false;
@@ -219,6 +220,8 @@ int finish_extract(ta_ctx* c) {
         if (c->pair_log2 >= 30) break;
         int rc = ensure_pair_table(c, c->pair_log2 + 2);
         if (rc != TA_OK) return rc;
+        if (c->reduced)       // a local re-run would replace the reduced (global) rows by this rank's: the host redoes the step
+            return fail(TA_ECAPACITY, "adjacency table overflow (grown to 2^%d slots): repeat the extraction on every rank", c->pair_log2);
         if ((rc = run_extract(c)) != TA_OK) return rc;
     }
     return fail(TA_ECAPACITY, "adjacency table overflow at 2^%d slots", c->pair_log2);
@@ -240,6 +243,8 @@ TA_API int ta_device_count(int* count) {
     return TA_OK;
 }
 
+TA_API int ta_ctx_destroy(ta_ctx* c);
+
 TA_API int ta_ctx_create(int device_id, ta_ctx** out) {
     if (!out) return fail(TA_EINVAL, "out is NULL");
     *out = nullptr;
@@ -252,13 +257,21 @@ TA_API int ta_ctx_create(int device_id, ta_ctx** out) {
     ta_ctx* c = new (std::nothrow) ta_ctx();
     if (!c) return fail(TA_ENOMEM, "out of host memory");
     c->device = device_id;
-    TA_HIP(hipSetDevice(device_id));
-    TA_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-    c->own_stream = true;
-    for (auto& e : c->ev) TA_HIP(hipEventCreate(&e));
-    int rc = c->small.reserve(SMALL_WORDS * sizeof(uint32_t));
-    if (rc != TA_OK) return rc;
-    TA_HIP(hipHostMalloc((void**)&c->h_small, SMALL_WORDS * sizeof(uint32_t), hipHostMallocDefault));
+    // every failure below goes through ta_ctx_destroy: it releases whatever was created so far
+    int rc = TA_OK;
+    hipError_t e = hipSetDevice(device_id);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) c->own_stream = true;
+    for (auto& ev : c->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+    if (e == hipSuccess) rc = c->small.reserve(SMALL_WORDS * sizeof(uint32_t));
+    if (e == hipSuccess && rc == TA_OK) e = hipHostMalloc((void**)&c->h_small, SMALL_WORDS * sizeof(uint32_t), hipHostMallocDefault);
+    if (e != hipSuccess || rc != TA_OK) {
+        if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? TA_ENOMEM : TA_EHIP, "ta_ctx_create: %s", hipGetErrorString(e));
+        const std::string keep = g_err;
+        (void)ta_ctx_destroy(c);
+        g_err = keep;
+        return rc;
+    }
     memset(c->h_small, 0, SMALL_WORDS * sizeof(uint32_t));
     *out = c;
     return TA_OK;
@@ -285,8 +298,12 @@ TA_API int ta_ctx_set_stream(ta_ctx* c, void* hip_stream) {
     int rc = use_device(c);
     if (rc != TA_OK) return rc;
     if (c->stream) TA_HIP(hipStreamSynchronize(c->stream));
-    if (c->own_stream && c->stream) { (void)hipStreamDestroy(c->stream); c->stream = nullptr; }
-    if (hip_stream) {
+    if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+    c->stream = nullptr;
+    if (hip_stream == TA_STREAM_LEGACY_DEFAULT) {
+        c->stream = hipStreamLegacy;              // the null stream: ordered with every blocking stream of the device
+        c->own_stream = false;
+    } else if (hip_stream) {
         c->stream = (hipStream_t)hip_stream;
         c->own_stream = false;
     } else {
@@ -453,6 +470,25 @@ TA_API int ta_volume_map(ta_ctx* c, const void* lut, uint32_t lut_len, const voi
     return TA_OK;
 }
 
+TA_API int ta_volume_first_layer(ta_ctx* c, uint32_t background, int keep_background, void* host_dst) {
+    if (!c || !host_dst) return fail(TA_EINVAL, "NULL argument");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    if (c->first_owned) return fail(TA_EINVAL, "the first voxel layer is not available on a slab that carries a halo plane");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t bytes = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2] * c->itemsize;
+    DevBuf dout;
+    if ((rc = dout.reserve(bytes)) != TA_OK) return rc;
+    ta::launch_first_layer(c->stream, c->vol, c->itemsize, dout.p, c->mdims[0], c->mdims[1], c->mdims[2], background,
+                           keep_background ? 1 : 0);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host_dst, dout.p, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dout.release();
+    if (e != hipSuccess) return fail(TA_EHIP, "first voxel layer: %s", hipGetErrorString(e));
+    return TA_OK;
+}
+
 TA_API int ta_wall_voxels_count(ta_ctx* c, int64_t* nrecords) {
     if (!c || !nrecords) return fail(TA_EINVAL, "NULL argument");
     if (!c->vol) return fail(TA_EINVAL, "no volume set");
@@ -461,17 +497,24 @@ TA_API int ta_wall_voxels_count(ta_ctx* c, int64_t* nrecords) {
     if (rc != TA_OK) return rc;
     const uint64_t chunks = ta::wall_chunks(c->mdims[0], c->mdims[1], c->mdims[2]);
     if ((rc = c->wall_counts.reserve(chunks * 8 + 8)) != TA_OK) return rc;
-    hipEvent_t e0, e1;
-    TA_HIP(hipEventCreate(&e0)); TA_HIP(hipEventCreate(&e1));
-    TA_HIP(hipEventRecord(e0, c->stream));
-    ta::launch_wall_count(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], (uint64_t*)c->wall_counts.p);
-    TA_HIP(hipEventRecord(e1, c->stream));
-    std::vector<uint64_t> h(chunks + 1, 0);
-    TA_HIP(hipMemcpyAsync(h.data(), c->wall_counts.p, chunks * 8, hipMemcpyDeviceToHost, c->stream));
-    TA_HIP(hipStreamSynchronize(c->stream));
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::vector<uint64_t> h;
+    try { h.assign(chunks + 1, 0); } catch (...) { return fail(TA_ENOMEM, "out of host memory"); }
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    if (e == hipSuccess) {
+        ta::launch_wall_count(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], (uint64_t*)c->wall_counts.p);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), c->wall_counts.p, chunks * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, e0, e1);
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(TA_EHIP, "wall voxel count: %s", hipGetErrorString(e));
     uint64_t run = 0;                                        // exclusive scan of the chunk counts
     for (uint64_t k = 0; k < chunks; ++k) { const uint64_t n = h[k]; h[k] = run; run += n; }
     TA_HIP(hipMemcpyAsync(c->wall_counts.p, h.data(), chunks * 8, hipMemcpyHostToDevice, c->stream));
@@ -581,13 +624,15 @@ TA_API int ta_extract(ta_ctx* c, uint32_t feature_mask, uint32_t max_label) {
     c->feature_mask = feature_mask;
     {
         const bool adj = feature_mask & TA_F_ADJACENCY;
-        int want = c->opt_pair_log2 ? c->opt_pair_log2
+        // never below a size the table has already grown to (a fixed TA_OPT_PAIR_SLOTS is a starting size)
+        int want = c->opt_pair_log2 ? std::max(c->opt_pair_log2, c->pkeys.p ? c->pair_log2 : 0)
                                     : std::max(c->pkeys.p ? c->pair_log2 : 4, adj ? auto_pair_log2(max_label) : 4);
         if ((rc = ensure_pair_table(c, want)) != TA_OK) return rc;
     }
     c->extracted = true;
     c->checked = false;
     c->exchanged = false;
+    c->reduced = false;
     c->host_pairs_ready = false;
     return run_extract(c);
 }
@@ -692,6 +737,13 @@ TA_API int ta_debug_counters(ta_ctx* c, uint32_t out[16]) {
     if (rc != TA_OK) return rc;
     TA_HIP(hipStreamSynchronize(c->stream));
     for (int i = 0; i < 16; ++i) out[i] = i < ta::NFLAGS ? c->h_small[i] : 0u;
+    return TA_OK;
+}
+
+TA_API int ta_accumulators_reduced(ta_ctx* c) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if (!c->extracted) return fail(TA_EINVAL, "no extraction has been run on this context");
+    c->reduced = true;
     return TA_OK;
 }
 

@@ -10,7 +10,8 @@ _TORCH_DTYPE = {"uint16": "int16", "uint32": "int32"}
 
 
 def torch_context(device=0):
-    """A C-ABI context that launches on torch's current stream of `device`."""
+    """A C-ABI context that launches on torch's current stream of `device` (torch's default stream is the
+    device's legacy null stream, handle 0: Context.set_stream maps that to TA_STREAM_LEGACY_DEFAULT)."""
     import torch
     torch.cuda.set_device(device)
     ctx = _capi.Context(device)

@@ -99,7 +99,12 @@ class SlabJob(object):
                  group=None, device=0, exchange_capacity=None, stream=None):
         import torch
         self.ctx, self.vol, self.group = ctx, vol_tensor, group
-        self.stream = stream                    # torch.cuda.Stream all of this job's work is ordered on, or None
+        # Kernels (C ABI) and collectives (torch.distributed) must be ordered on ONE stream: the torch stream given
+        # here, else torch's current stream at construction -- never a private stream of the context, which nothing
+        # orders against the stream RCCL enqueues on.
+        if stream is None and vol_tensor.is_cuda:
+            stream = torch.cuda.current_stream(vol_tensor.device)
+        self.stream = stream                    # torch.cuda.Stream all of this job's work is ordered on
         if stream is not None:
             ctx.set_stream(stream.cuda_stream)
         self.has_low_halo = bool(has_low_halo)
@@ -125,22 +130,47 @@ class SlabJob(object):
         from . import _capi
         return self.group is not None and bool(_capi.feature_mask(self.features) & _capi.F_ADJACENCY)
 
+    # verdict words shared by all ranks (MAX over ranks decides)
+    _OK, _CAPACITY, _RANGE, _FAILED = 0, 1, 2, 3
+
+    def _local_verdict(self):
+        """(pair count, status) of this rank's last extraction; never raises: the status is agreed on collectively."""
+        from . import _capi
+        try:
+            return self.ctx.adjacency_size(), self._OK, None     # drains this job's stream, validates the flags
+        except _capi.TissueScanError as e:
+            code = {_capi.TA_ECAPACITY: self._CAPACITY, _capi.TA_ERANGE: self._RANGE}.get(e.code, self._FAILED)
+            return 0, code, e
+
+    def _raise_collectively(self, status, own_error):
+        """Every rank leaves with an exception of the same kind."""
+        from . import _capi
+        if status == self._RANGE:
+            raise _capi.TissueScanError(_capi.TA_ERANGE, "a rank's slab holds a label above max_label=%d" % self.max_label)
+        if own_error is not None:
+            raise own_error
+        raise RuntimeError("the extraction failed on another rank of the group")
+
     def _agree_on_sizes(self):
         """One-off and synchronous: block capacity from the largest local pair list, one table
-        size for all ranks.  Returns True when the extraction had to be repeated."""
+        size for all ranks.  Returns True when the extraction had to be repeated.  A failure on any
+        rank (label above max_label, HIP error ...) is raised on EVERY rank after the collective."""
         import torch.distributed as dist
         from . import _capi
         torch = self._torch
-        n = self.ctx.adjacency_size()                      # drains; a local table overflow re-runs inside
+        n, status, err = self._local_verdict()         # a local table overflow re-runs inside
         slots = self.ctx.get_option(_capi.OPT_PAIR_SLOTS)
-        t = torch.tensor([n, slots], dtype=torch.int64, device=self.sums.device)
+        t = torch.tensor([n, slots, status], dtype=torch.int64, device=self.sums.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        nmax, smax = [int(x) for x in t.tolist()]
+        nmax, smax, status = [int(x) for x in t.tolist()]
+        if status not in (self._OK, self._CAPACITY):
+            self._unverified = False
+            self._raise_collectively(status, err)
         if self._cap is None:
             self._cap = max(1024, -(-(nmax + nmax // 4 + 1) // 1024) * 1024)
-        again = smax != slots
+        again = smax != slots or status == self._CAPACITY
         if again:
-            self.ctx.set_option(_capi.OPT_PAIR_SLOTS, smax)
+            self.ctx.set_option(_capi.OPT_PAIR_SLOTS, max(smax, self.ctx.get_option(_capi.OPT_PAIR_SLOTS)))
             self.ctx.extract(self.features, self.max_label)
         return again
 
@@ -180,6 +210,7 @@ class SlabJob(object):
         if adj and (self._cap is None or self._send is None):
             self._agree_on_sizes()
         allreduce_accumulators(self.sums, self.boxes, self.group)
+        self.ctx.accumulators_reduced()          # from here on a local re-run would lose the other ranks' rows
         if adj:
             world = self._exchange_buffers()
             self.ctx.adjacency_pack(self._send.data_ptr(), self._cap)
@@ -198,23 +229,16 @@ class SlabJob(object):
         from . import _capi
         torch = self._torch
         for attempt in range(6):
-            status = 0
-            try:
-                self.ctx.adjacency_size()                  # drains this job's stream, validates the flags
-            except _capi.TissueScanError as e:
-                if e.code not in (_capi.TA_ECAPACITY, _capi.TA_ERANGE):
-                    raise
-                status = 1 if e.code == _capi.TA_ECAPACITY else 2
+            _, status, err = self._local_verdict()
             t = torch.tensor([status], dtype=torch.int64, device=self.sums.device)
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
             status = int(t.item())
-            if status == 0:
+            if status == self._OK:
                 self._unverified = False
                 return
-            if status == 2:                                # same exception on every rank
+            if status != self._CAPACITY:                   # same kind of exception on every rank
                 self._unverified = False
-                raise _capi.TissueScanError(_capi.TA_ERANGE, "a rank's slab holds a label above max_label=%d"
-                                            % self.max_label)
+                self._raise_collectively(status, err)
             self.redo_count += 1
             self._cap = None
             self._send = self._recv = None

@@ -130,6 +130,16 @@ class Extraction(object):
             return []
         return [int(v) for v in dst[ptr[label]:ptr[label + 1]]]
 
+    def surface_faces(self, labels):
+        """uint64 [n, 3]: per-axis number of voxel faces each label shares with ANY other label (faces on the border
+        of the volume belong to no wall and are not counted): the row sums of the adjacency."""
+        out = np.zeros((self.max_label + 2, 3), dtype=np.uint64)
+        np.add.at(out, self.pair_lo.astype(np.int64), self.pair_faces)
+        np.add.at(out, self.pair_hi.astype(np.int64), self.pair_faces)
+        idx = np.asarray(labels, dtype=np.int64)
+        idx = np.where((idx >= 0) & (idx <= self.max_label), idx, self.max_label + 1)     # unknown labels: the zero row
+        return out[idx]
+
     def faces_between(self, label, others):
         """uint64 [len(others), 3]: per-axis shared-face counts of (label, other); 0 when not adjacent."""
         ptr, dst, pid = self._adjacency_csr()
@@ -163,6 +173,92 @@ def extract_resident(ctx, shape, features=_capi.F_ALL, max_label=None):
     return Extraction(shape, max_label, count, bbox, sum1, sum2, lo, hi, faces, ctx.timing())
 
 
+def _as_label_volume(array):
+    """uint16 / uint32 view or copy of an integer label image, 3-D (a 2-D image becomes (X, Y, 1)), dense in some
+    axis permutation.  Returns (volume, is_view_of_input)."""
+    a = np.asarray(array)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    if a.ndim != 3:
+        raise ValueError("a 2-D or 3-D label image is required")
+    same = True
+    if a.dtype not in (np.uint16, np.uint32):
+        if not np.issubdtype(a.dtype, np.integer):
+            raise TypeError("label images must be integer arrays, not %s" % a.dtype)
+        if a.size and (a.min() < 0 or a.max() > np.iinfo(np.uint32).max):
+            raise ValueError("labels must fit in uint32")
+        a = a.astype(np.uint16 if (a.size == 0 or a.max() <= 65535) else np.uint32)
+        same = False
+    if not _capi._dense_permuted(a):
+        a = np.ascontiguousarray(a)
+        same = False
+    return a, same
+
+
+class ResidentVolume(object):
+    """One label image uploaded ONCE to one GPU context and kept there: the sweep, the wall-voxel extraction, the
+    label lookup-table passes and the first voxel layer all run on the resident copy (the reference re-scans the
+    host image for each of them; round 1 of this build re-uploaded it for each).  `uploads` counts H2D copies."""
+
+    def __init__(self, array, device=0):
+        self.host, self.is_input = _as_label_volume(array)
+        self.device = device
+        self.ctx = _capi.Context(device)
+        self.uploads = 0
+        self.ms = {}                  # wall-clock milliseconds of the last upload / sweep / fetch (host side)
+        self.upload()
+
+    def close(self):
+        if self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, array=None):
+        """(Re-)upload: after construction, or after the host image was modified in place."""
+        import time
+        if array is not None:
+            self.host, self.is_input = _as_label_volume(array)
+        t0 = time.perf_counter()
+        self.ctx.set_volume(self.host)
+        self.ms["upload"] = (time.perf_counter() - t0) * 1e3
+        self.uploads += 1
+
+    def extract(self, features=_capi.F_ALL, max_label=None):
+        import time
+        t0 = time.perf_counter()
+        x = extract_resident(self.ctx, self.host.shape, features, max_label)
+        self.ms["extract"] = (time.perf_counter() - t0) * 1e3
+        return x
+
+    def wall_table(self):
+        lo, hi, coords, ms = self.ctx.wall_voxels()
+        if not self.host.flags.c_contiguous and coords.shape[0]:   # records come in memory order: np.where order wanted
+            order = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
+            lo, hi, coords = lo[order], hi[order], coords[order]
+        return WallTable(lo, hi, coords, ms)
+
+    def relabel(self, lut, features=_capi.F_ALL):
+        """v -> lut[v] on the resident volume AND on `self.host` (copied back), then sweep the new volume."""
+        self.ctx.relabel(lut)
+        if not self.host.flags.writeable:
+            self.host = self.host.copy()
+            self.is_input = False
+        self.ctx.get_volume(self.host)
+        return self.extract(features)
+
+    def map(self, lut, fill):
+        return self.ctx.map_labels(lut, fill, self.host)
+
+    def first_layer(self, background, keep_background=True):
+        return self.ctx.first_layer(background, keep_background, self.host)
+
+
 def extract_volume(array, features=_capi.F_ALL, device=0, context=None, max_label=None,
                    impl=None, tile_planes=None):
     """Upload `array` (uint16/uint32, any dense layout) and run the fused sweep on the GPU."""
@@ -187,31 +283,23 @@ def relabel_volume(array, lut, features=_capi.F_ALL, device=0):
     """One upload: relabel `array` IN PLACE through `lut` on the GPU (v -> lut[v] for v < len(lut)),
     copy it back, and sweep the relabelled volume.  `array` must be a writeable dense uint16/uint32
     ndarray (any axis permutation).  Returns the Extraction of the new volume."""
-    a = array if array.ndim == 3 else array[:, :, None]
-    ctx = _capi.Context(device)
+    rv = ResidentVolume(array, device)
     try:
-        ctx.set_volume(a)
-        ctx.relabel(lut)
-        ctx.get_volume(a)
-        return extract_resident(ctx, a.shape, features)
+        if not rv.is_input:
+            raise TypeError("relabel_volume needs a writeable dense uint16 / uint32 array")
+        return rv.relabel(lut, features)
     finally:
-        ctx.close()
+        rv.close()
 
 
 def map_volume(array, lut, fill, device=0):
     """out[p] = lut[array[p]] (fill beyond the table) on the GPU; `lut` fixes the output dtype."""
-    a = np.asarray(array)
-    flat = a.ndim == 2
-    if flat:
-        a = a[:, :, None]
-    if a.dtype not in (np.uint16, np.uint32) or not _capi._dense_permuted(a):
-        a = np.ascontiguousarray(a, dtype=np.uint16 if a.dtype.itemsize <= 2 else np.uint32)
-    ctx = _capi.Context(device)
+    flat = np.asarray(array).ndim == 2
+    rv = ResidentVolume(array, device)
     try:
-        ctx.set_volume(a)
-        out = ctx.map_labels(lut, fill, a)
+        out = rv.map(lut, fill)
     finally:
-        ctx.close()
+        rv.close()
     return out[:, :, 0] if flat else out
 
 
@@ -249,20 +337,8 @@ class WallTable(object):
 
 def wall_voxel_table(array, device=0):
     """Upload `array` and extract the wall voxels of all label pairs (18-neighbourhood) on the GPU."""
-    a = np.asarray(array)
-    if a.ndim == 2:
-        a = a[:, :, None]
-    if a.dtype not in (np.uint16, np.uint32):
-        wide = a.size and int(a.max()) > 65535
-        a = np.ascontiguousarray(a, dtype=np.uint32 if wide else np.uint16)
-    c_order = a.flags.c_contiguous
-    ctx = _capi.Context(device)
+    rv = ResidentVolume(array, device)
     try:
-        ctx.set_volume(a)
-        lo, hi, coords, ms = ctx.wall_voxels()
+        return rv.wall_table()
     finally:
-        ctx.close()
-    if not c_order and coords.shape[0]:          # records come in memory order: put them in np.where order
-        order = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
-        lo, hi, coords = lo[order], hi[order], coords[order]
-    return WallTable(lo, hi, coords, ms)
+        rv.close()

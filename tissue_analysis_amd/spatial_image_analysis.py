@@ -28,6 +28,7 @@ import numpy as np
 
 from . import _capi
 from .extraction import Extraction, extract_volume
+from .geometry import _find_wall_median_voxel, find_wall_median_voxel, geometric_median   # module-level in SIA too (SIA:1499-1635)
 from .spatial_image import SpatialImage
 
 NPLIST, LIST, DICT = range(3)  # SIA:204
@@ -101,6 +102,8 @@ class AbstractSpatialImageAnalysis(object):
             pass
         self.return_type = return_type
         self._device = device
+        self._rv = None
+        self._voxel_layer1 = None
         self._x = extraction if extraction is not None else self._sweep()
         if background is not None:
             if not self._x.has(int(background)):
@@ -109,19 +112,20 @@ class AbstractSpatialImageAnalysis(object):
         else:
             warnings.warn("No value defining the background, some functionalities won't work !")
 
-    # -- the only place voxels are touched: one fused sweep on the GPU
+    # -- the only place voxels are touched: ONE upload per analysis object, one fused sweep on the GPU; the wall
+    # voxels, the relabelling passes, the property images and the first voxel layer reuse the resident copy
+    def _resident(self):
+        from .extraction import ResidentVolume
+        if getattr(self, "_rv", None) is None:
+            self._rv = ResidentVolume(np.asarray(self.image), device=self._device)
+        return self._rv
+
     def _sweep(self):
-        vol = np.asarray(self.image)
-        if vol.dtype not in (np.uint16, np.uint32):
-            if not np.issubdtype(vol.dtype, np.integer):
-                raise TypeError("label images must be integer arrays, not %s" % vol.dtype)
-            if vol.size and (vol.min() < 0 or vol.max() > np.iinfo(np.uint32).max):
-                raise ValueError("labels must fit in uint32")
-            vol = vol.astype(np.uint16 if (vol.size == 0 or vol.max() <= 65535) else np.uint32)
-        return extract_volume(vol, _capi.F_ALL, device=self._device)
+        return self._resident().extract(_capi.F_ALL)
 
     def refresh(self):
-        """Re-run the sweep after ``self.image`` was modified in place."""
+        """Re-upload and re-run the sweep after ``self.image`` was modified in place."""
+        self._resident().upload(np.asarray(self.image))
         self._x = self._sweep()
         self._labels = None
         self._bbox = None
@@ -129,6 +133,7 @@ class AbstractSpatialImageAnalysis(object):
         self._cell_layer1 = None
         self._center_of_mass = {}
         self._walls = None
+        self._voxel_layer1 = None
 
     @property
     def extraction(self):
@@ -349,6 +354,19 @@ class AbstractSpatialImageAnalysis(object):
                     areas[key] = areas.get(key, 0.0) + val
         return areas
 
+    def surface_area(self, labels=None, real=True):
+        """Per-label total surface area = the sum of the label's wall areas with all its face neighbours
+        (SURVEY.md §8 "Semantics": sum_m wall_area(l, m); the reference has no dedicated method, `cell_wall_area`
+        SIA:908-959 gives it one wall at a time).  real: F0 vy vz + F1 vz vx + F2 vx vy; else the number of faces."""
+        single = isinstance(labels, _INT)
+        req = [int(labels)] if single else self.label_request(labels)
+        faces = self._x.surface_faces(req).astype(np.float64)
+        if real:
+            area = faces @ np.asarray(self.get_voxel_face_surface(), dtype=np.float64)
+        else:
+            area = faces.sum(axis=1)
+        return float(area[0]) if single else self.convert_return(area, req)
+
     # -- layers and margins (SIA:996-1022): host post-processing of the sweep results
     def cell_first_layer(self, filter_by_area=True, minimal_external_area=10, real_area=True):
         if self._cell_layer1 is None:
@@ -371,12 +389,26 @@ class AbstractSpatialImageAnalysis(object):
         return self._cell_layer2
 
 
+    # -- first voxel layer (SIA:1024-1046): `image * (dilate6(image == bg) - (image == bg)) + (image == bg)` as one
+    # 6-stencil pass over the resident volume on the GPU
+    def voxel_first_layer(self, keep_background=True):
+        """First layer of voxels in contact with the background: they keep their label, the rest of the tissue
+        becomes 0, the background 1 (keep_background) or 0.  Cached like in the reference (the first call's
+        `keep_background` wins, SIA:1044-1046)."""
+        if self._voxel_layer1 is None:
+            layer = self._resident().first_layer(self.background(), keep_background)
+            img = np.asarray(self.image)
+            if img.ndim == 2:
+                layer = layer[:, :, 0]
+            self._voxel_layer1 = SpatialImage(layer.astype(img.dtype, copy=False),
+                                              voxelsize=getattr(self.image, "voxelsize", None))
+        return self._voxel_layer1
+
     # -- wall voxels (SIA:759-880, 1049-1111): one GPU pass finds the wall voxels of EVERY pair (18-neighbourhood
     # contact, scipy's generate_binary_structure(3, 2)); the methods below are lookups in that table.
     def wall_table(self):
         if self._walls is None:
-            from .extraction import wall_voxel_table
-            self._walls = wall_voxel_table(np.asarray(self.image), device=self._device)
+            self._walls = self._resident().wall_table()
         return self._walls
 
     def wall_voxels_between_two_cells(self, label_1, label_2, bbox=None, verbose=False):  # SIA:759-806
@@ -412,13 +444,17 @@ class AbstractSpatialImageAnalysis(object):
     def wall_voxels_per_cells_pairs(self, labels=None, neighborhood=None, only_epidermis=False,
                                     ignore_background=False, min_contact_area=None, real_area=True,
                                     verbose=True):  # SIA:1049-1111
-        if only_epidermis:
-            raise NotImplementedError("only_epidermis needs voxel_first_layer (SIA:1024-1046), which is not built")
+        # only_epidermis (SIA:1062-1065, 1073-1076): the reference takes the first voxel layer, but then only uses it
+        # for the DEFAULT label list (np.unique of that image: 0 = emptied interior, 1 = background, and the labels
+        # that touch the background); the walls themselves are still found on the full image (SIA:826, 1108)
+        image = self.voxel_first_layer(True) if only_epidermis else None
         compute_neighborhood = neighborhood is None
         if isinstance(labels, list) and isinstance(neighborhood, dict):
             labels = [label for label in labels if label in neighborhood]
-        if labels is None:
+        if labels is None and not only_epidermis:
             labels = self.labels()
+        elif labels is None and only_epidermis:
+            labels = [int(v) for v in np.unique(np.asarray(image))]
         elif isinstance(labels, list):
             labels.sort()
             if not isinstance(neighborhood, dict):
@@ -448,23 +484,19 @@ class AbstractSpatialImageAnalysis(object):
     # The reference leaves its caches (_labels, _bbox, _neighbors ...) stale after these calls; here the
     # relabelled volume is swept again in the same upload, so every later answer describes the new image.
     def _relabel_image(self, mapping):
-        from .extraction import relabel_volume
-        img = np.asarray(self.image)
-        work = img if img.ndim == 3 else img[:, :, None]
-        direct = work.dtype in (np.uint16, np.uint32) and _capi._dense_permuted(work) and work.flags.writeable
-        if not direct:
-            wide = work.size and int(work.max()) > 65535
-            work = np.ascontiguousarray(work, dtype=np.uint32 if wide else np.uint16)
-        top = np.iinfo(work.dtype).max
+        rv = self._resident()
+        top = np.iinfo(rv.host.dtype).max
         lut = np.arange(self._x.max_label + 1, dtype=np.uint32)
         for old, new in mapping.items():
             if not (0 <= int(new) <= top):
-                raise ValueError("value %r does not fit the image dtype %s" % (new, work.dtype))
+                raise ValueError("value %r does not fit the image dtype %s" % (new, rv.host.dtype))
             if 0 <= int(old) <= self._x.max_label:
                 lut[int(old)] = int(new)
-        x = relabel_volume(work, lut, device=self._device)
-        if not direct:
-            np.copyto(self.image if img.ndim == 3 else self.image[:, :, None], work.astype(img.dtype), casting="unsafe")
+        x = rv.relabel(lut)                       # resident volume and rv.host are relabelled; no new upload
+        img = np.asarray(self.image)
+        target = img if img.ndim == 3 else img[:, :, None]
+        if not np.shares_memory(target, rv.host):          # the image had another dtype / layout: write it back
+            np.copyto(target, rv.host.astype(img.dtype), casting="unsafe")
         self._x = x
         self._labels = None
         self._bbox = None
@@ -472,6 +504,7 @@ class AbstractSpatialImageAnalysis(object):
         self._cell_layer1 = None
         self._center_of_mass = {}
         self._walls = None
+        self._voxel_layer1 = None
 
     def fuse_labels_in_image(self, labels, verbose=True):  # SIA:1114-1136
         """Modify the image so the given labels are fused (to the min value)."""
@@ -506,7 +539,6 @@ class AbstractSpatialImageAnalysis(object):
         """Image of a per-label property (PropertySpatialImage.create_property_image, PSI:207-221):
         labels without a value, and the background, map to the background id; values are cast with
         ``astype(dtype)`` per label, which is what the reference does per voxel."""
-        from .extraction import map_volume
         bg = self.background()
         if bg is None:
             raise ValueError("property_image needs the background label")
@@ -517,7 +549,9 @@ class AbstractSpatialImageAnalysis(object):
                 lut[int(l)] = v
         with np.errstate(invalid="ignore"):
             lut = lut.astype(dtype)
-        out = map_volume(np.asarray(self.image), lut, np.array(bg).astype(dtype), device=self._device)
+        out = self._resident().map(lut, np.array(bg).astype(dtype))
+        if np.asarray(self.image).ndim == 2:
+            out = out[:, :, 0]
         return SpatialImage(out, voxelsize=getattr(self.image, "voxelsize", None))
 
 
