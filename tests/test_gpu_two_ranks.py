@@ -78,3 +78,106 @@ def test_two_ranks_on_one_gpu_match_unsharded(dims, n_cells, dtype_name, capacit
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] for r in results), results
+
+
+def _nccl_worker(rank, world, port, dims, n_cells, seed, q):
+    """World size 1 over RCCL: the same SlabJob code path as a multi-GPU run (all-reduce, packed all-gather, merge of the
+    gathered blocks), with torch.distributed's nccl backend on the one GPU of this box."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    try:
+        from oracle import onepass_c
+        from tissue_analysis_amd import _capi, device as dev, distributed as tad, synth
+        dtype = np.dtype("uint32")
+        ctx = dev.torch_context(0)
+        vol, max_label = dev.synth_slab(ctx, dims, dtype, n_cells, seed, 0, dims[0], device=0)
+        job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=0, has_low_halo=False, max_label=max_label,
+                          features=_capi.F_ALL, group=dist.group.WORLD, device=0)
+        for _ in range(3):
+            job.step()
+        got = job.result_arrays()
+        want = onepass_c.extract(synth.voronoi_labels(dims, n_cells, seed, dtype), max_label=max_label)
+        bad = [k for k in ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces")
+               if not (got[k].shape == want[k].shape and np.array_equal(got[k], want[k]))]
+        pipe = tad.PipelinedSlabJob(vol, dtype.itemsize, a_origin=0, has_low_halo=False, max_label=max_label,
+                                    features=_capi.F_ALL, group=dist.group.WORLD, device=0, depth=2)
+        for _ in range(4):
+            pipe.step()
+        got2 = pipe.result_arrays()
+        bad += ["pipelined " + k for k in ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces")
+                if not np.array_equal(got2[k], want[k])]
+        q.put((rank, not bad, bad))
+        pipe.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world_size_one_over_rccl():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 400)
+    p = ctx.Process(target=_nccl_worker, args=(0, 1, port, (96, 128, 512), 400, 71, q))
+    p.start()
+    res = q.get(timeout=300)
+    p.join(timeout=60)
+    assert p.exitcode == 0 and res[1], res
+
+
+def _range_worker(rank, world, port, q):
+    """Only rank 1's slab holds a label above max_label: BOTH ranks must leave with TA_ERANGE (no rank may be left
+    waiting in a collective) -- on the very first step, where the sizes are agreed on, and on a later one."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tissue_analysis_amd import _capi, device as dev, distributed as tad
+        dims, dtype = (24, 32, 256), np.dtype("uint32")
+        ctx = dev.torch_context(0)
+        lo, hi = tad.slab_range(dims[0], world, rank)
+        halo = 1 if lo > 0 else 0
+        vol, max_label = dev.synth_slab(ctx, dims, dtype, 30, 72, lo - halo, hi, device=0)
+        outcomes = []
+        for first in (True, False):
+            job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=lo, has_low_halo=bool(halo), max_label=max_label,
+                              features=_capi.F_ALL, group=dist.group.WORLD, device=0)
+            if not first:
+                job.step()
+                job.finish()
+            if rank == 1:
+                vol[3, 5, 7] = max_label + 5
+            try:
+                job.step()
+                job.finish()
+                outcomes.append("no error")
+            except _capi.TissueScanError as e:
+                outcomes.append("ERANGE" if e.code == _capi.TA_ERANGE else "code %d" % e.code)
+            if rank == 1:
+                vol[3, 5, 7] = 1
+        q.put((rank, outcomes == ["ERANGE", "ERANGE"], outcomes))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_a_range_error_on_one_rank_is_raised_on_every_rank():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29100 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_range_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in results), results
