@@ -10,10 +10,15 @@ reduce and the adjacency merge).  N = 1 runs BASELINE.json's metric config (C4: 
 ~50k seeds, full feature set).  N > 1 is weak scaling with the same voxel count per GPU, Z-slab
 partitioned with a one-plane halo; N = 8 is exactly config C5 (2048^3, 100k seeds).
 
-Rank 0 prints ONE JSON line (contract in the task description), with two extra objects:
-  roofline     -- the sweep kernel's algorithmic bytes / its mean HIP-event duration vs 8 TB/s
+Rank 0 prints ONE JSON line (contract in the task description), with extra objects:
+  roofline     -- the sweep kernel's algorithmic bytes / its mean HIP-event duration vs 8 TB/s, plus
+                  `peak_measured`: what a trivial 16-B/lane read-reduce kernel reaches on the same buffer in this run
   cpu_baseline -- the per-label scipy restatement of the reference (oracle/, 1 core) timed on a
-                  bounded crop of the same volume on this node's host (rank 0, N = 1 only)
+                  bounded crop of the same volume on this node's host (rank 0, N = 1 only); `best_effort`
+                  inside it = the one-pass C restatement on 16 host processes (NOT the reference's algorithm)
+  secondary    -- (N = 1) the same volume WITHOUT the ellipsoid mask: tissue everywhere, ~50k labels present,
+                  2.6x the event density of the headline workload; and the headline workload with two steps in flight
+                  (what N > 1 runs), so that a scaling curve compares like with like
 """
 from __future__ import annotations
 
@@ -68,6 +73,42 @@ def cpu_baseline(vol_tensor, dims, dtype, edge=400):
                 host_cpus=os.cpu_count())
 
 
+def _slab_worker(args):
+    """Best-effort CPU: one Z-slab of the sample through the one-pass C restatement (own process: it keeps globals)."""
+    from oracle import onepass_c
+    lo, hi, L = args
+    vol = _BE_SAMPLE              # inherited through fork: no pickling of the voxels
+    halo = 1 if lo > 0 else 0
+    return onepass_c.extract(vol[lo - halo:hi], max_label=L, origin=(lo - halo, 0, 0), own_first_plane=not halo)
+
+
+_BE_SAMPLE = None
+
+
+def cpu_best_effort(vol_tensor, dims, dtype, max_label, planes=256, workers=16):
+    """The build's own one-pass formulation on `workers` host processes (BASELINE.md §4 "best-effort CPU")."""
+    import multiprocessing as mp
+    from oracle import onepass, onepass_c
+    onepass_c.build()
+    planes = min(planes, dims[0])
+    lo0 = (dims[0] - planes) // 2
+    sample = vol_tensor[lo0:lo0 + planes].contiguous().cpu().numpy().view(np.dtype(dtype))
+    global _BE_SAMPLE
+    _BE_SAMPLE = sample
+    cuts = [planes * i // workers for i in range(workers + 1)]
+    jobs = [(a, b, max_label) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(len(jobs)) as pool:
+        parts = pool.map(_slab_worker, jobs)
+    merged = onepass.merge(parts)
+    dt = time.perf_counter() - t0
+    _BE_SAMPLE = None
+    return dict(value=round(sample.size / dt / 1e6, 1), unit="Mvoxels/s", cores=len(jobs), kind="port",
+                sample="%d central planes of the bench volume (%d labels), one-pass C restatement (oracle/onepass_c.c) on %d "
+                       "processes + merge, %.1f s; NOT the reference's algorithm" % (planes, int((merged["count"] > 0).sum()),
+                                                                                      len(jobs), dt))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -77,6 +118,8 @@ def main():
     ap.add_argument("--features", type=lambda v: int(v, 0), default=None,
                     help="override the feature mask (e.g. 0x0f = everything but adjacency); not the headline metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the tissue-filled and the two-steps-in-flight figures")
+    ap.add_argument("--no-ellipsoid", action="store_true", help="tissue everywhere (not the headline workload)")
     ap.add_argument("--tile-planes", type=int, default=0)
     ap.add_argument("--dims", type=int, nargs=3, default=None, help="rehearsal: override the volume shape")
     args = ap.parse_args()
@@ -128,7 +171,9 @@ def main():
     a_lo, a_hi = tad.slab_range(dims[0], n, rank)
     halo = 1 if a_lo > 0 else 0
     vol, max_label = dev.synth_slab(ctx, dims, dtype, cfg["n_cells"], cfg["seed"], a_lo - halo, a_hi,
-                                    device=local_rank)
+                                    device=local_rank, ellipsoid=not args.no_ellipsoid)
+    if args.no_ellipsoid:
+        cfg = dict(cfg, name=cfg["name"] + "-filled")
     # N > 1: two steps in flight on two streams, so that step i's RCCL reduce / adjacency exchange
     # overlaps step i+1's sweep (TA_BENCH_PIPELINE=1 turns the overlap off)
     depth = int(os.environ.get("TA_BENCH_PIPELINE", "2")) if n > 1 else 1
@@ -184,6 +229,9 @@ def main():
         labels_present = int((job.result_counts() > 0).sum())
         sweep = float(np.mean(sweep_ms))
         achieved = bytes_read / (sweep * 1e-3) / 1e9
+        owned = job.owned_view()
+        probe_ms = last_ctx().read_probe(owned.data_ptr(), owned.numel() * owned.element_size(), repeats=5)
+        peak_measured = owned.numel() * owned.element_size() / (probe_ms * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
         if os.path.exists(pmc):
@@ -204,13 +252,55 @@ def main():
                        "pct_hbm_roofline": round(100.0 * achieved / HBM_PEAK_GBS, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "peak_measured": round(peak_measured, 1), "frac_of_measured": round(achieved / peak_measured, 4),
                          "kernel": "scan_kernel",
                          "kernel_ms": round(sweep, 4),
                          "adjacency_collect_ms": round(float(np.mean(adj_ms)), 4),
                          "algorithmic_bytes_per_launch": int(bytes_read)},
         }
+        if n == 1 and not args.no_secondary and not args.config and args.features is None and not args.dims \
+                and not args.no_ellipsoid:
+            sec = {}
+            # (a) two steps in flight on two streams: what N > 1 runs
+            pj = tad.PipelinedSlabJob(vol, dtype.itemsize, a_origin=a_lo, has_low_halo=bool(halo), max_label=max_label,
+                                      features=feats, group=None, device=local_rank, depth=2, tile_planes=args.tile_planes)
+            for _ in range(args.warmup):
+                pj.step()
+            pj.finish(); torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                pj.step()
+            pj.finish(); torch.cuda.synchronize()
+            dt2 = time.perf_counter() - t1
+            pj.close()
+            sec["two_steps_in_flight"] = {"ms_per_step": round(dt2 / args.steps * 1e3, 4),
+                                          "value": round(nvox * args.steps / dt2 / 1e6, 1), "unit": "Mvoxels/s"}
+            # (b) tissue everywhere: same shape and seeds, no ellipsoid mask
+            del pj
+            vol2, _ = dev.synth_slab(ctx, dims, dtype, cfg["n_cells"], cfg["seed"], 0, dims[0], device=local_rank,
+                                     ellipsoid=False)
+            torch.cuda.synchronize()
+            job2 = tad.SlabJob(ctx, vol2, dtype.itemsize, a_origin=0, has_low_halo=False, max_label=max_label,
+                               features=feats, group=None, device=local_rank)
+            for _ in range(args.warmup):
+                job2.step()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                job2.step()
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t1
+            k_ms = ctx.timing()["ms_sweep"]
+            sec["tissue_filled"] = {"workload": "%s without the ellipsoid mask: %d labels present" % (
+                                        cfg["name"], int((job2.result_counts() > 0).sum())),
+                                    "ms_per_step": round(dt3 / args.steps * 1e3, 4),
+                                    "value": round(nvox * args.steps / dt3 / 1e6, 1), "unit": "Mvoxels/s",
+                                    "kernel_ms": round(k_ms, 4), "roofline_frac": round(bytes_read / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            del vol2, job2
+            out["secondary"] = sec
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(job.owned_view(), (a_hi - a_lo, dims[1], dims[2]), dtype)
+            out["cpu_baseline"]["best_effort"] = cpu_best_effort(job.owned_view(), (a_hi - a_lo, dims[1], dims[2]), dtype, max_label)
         print(json.dumps(out), flush=True)
     if n > 1:
         dist.barrier()

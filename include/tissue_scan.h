@@ -124,6 +124,11 @@ TA_API int ta_adjacency_get(ta_ctx* ctx, uint32_t* lo, uint32_t* hi, uint64_t* f
 TA_API int ta_timing(ta_ctx* ctx, double* ms_sweep, double* ms_adjacency, double* ms_total,
               uint64_t* bytes_read);
 
+/* Read-bandwidth probe: the best of `repeats` timed launches (HIP events on the context stream) of a
+ * trivial 16-bytes-per-lane read + XOR-reduce kernel over `bytes` of device memory: the streaming ceiling the box
+ * actually reaches, next to the 8 TB/s of the data sheet.  Reads only. */
+TA_API int ta_read_probe(ta_ctx* ctx, const void* dev_ptr, uint64_t bytes, int repeats, double* ms_best);
+
 /* Diagnostics of the last ta_extract: out[0] = label-range flag, out[1] = adjacency-table overflow
  * flag, out[2] = run records that missed the workgroup LDS label table (went to global atomics),
  * out[3] = face records that missed the LDS pair table, out[4..15] reserved (cycle stamps of

@@ -28,7 +28,7 @@ SYMBOLS = (
     "ta_volume_set_device", "ta_volume_max_label", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
     "ta_volume_first_layer", "ta_wall_voxels_count", "ta_wall_voxels_get",
     "ta_extract", "ta_get_labels",
-    "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_debug_counters", "ta_bind_accumulators",
+    "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_read_probe", "ta_debug_counters", "ta_bind_accumulators",
     "ta_accumulators_device", "ta_accumulators_reduced", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge",
     "ta_adjacency_pack", "ta_adjacency_merge_blocks", "ta_synth_voronoi",
     "ta_device_malloc", "ta_device_free", "ta_memcpy_d2h", "ta_memcpy_h2d",
@@ -86,6 +86,7 @@ def load():
         "ta_adjacency_size": (ci, [vp, P(i64)]),
         "ta_adjacency_get": (ci, [vp, vp, vp, vp]),
         "ta_timing": (ci, [vp, P(ctypes.c_double), P(ctypes.c_double), P(ctypes.c_double), P(u64)]),
+        "ta_read_probe": (ci, [vp, vp, u64, ci, P(ctypes.c_double)]),
         "ta_debug_counters": (ci, [vp, P(u32)]),
         "ta_bind_accumulators": (ci, [vp, vp, vp, u32]),
         "ta_accumulators_device": (ci, [vp, P(vp), P(vp), P(u32)]),
@@ -308,6 +309,12 @@ class Context(object):
         _check(self._lib.ta_timing(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(t),
                                    ctypes.byref(nbytes)))
         return dict(ms_sweep=a.value, ms_adjacency=b.value, ms_total=t.value, bytes_read=nbytes.value)
+
+    def read_probe(self, dev_ptr, nbytes, repeats=5):
+        """Milliseconds of the fastest of `repeats` read-only streaming passes over a device buffer."""
+        ms = ctypes.c_double(0.0)
+        _check(self._lib.ta_read_probe(self._h, ctypes.c_void_p(int(dev_ptr)), int(nbytes), int(repeats), ctypes.byref(ms)))
+        return ms.value
 
     def debug_counters(self):
         out = (ctypes.c_uint32 * 16)()

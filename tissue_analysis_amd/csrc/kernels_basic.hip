@@ -387,6 +387,31 @@ static void launch_map_t(hipStream_t s, const void* vol, void* out, int out_item
 }
 
 // ------------------------------------------------------------------------------------------
+// Read-bandwidth probe ("measure the box's achievable read-only streaming bandwidth with a trivial
+// reduction kernel"): 16-byte loads, four in flight per lane, an XOR reduction nobody needs; the sink store can
+// never happen (the data are labels < 2^32, never all-ones four times over) but keeps the loads alive.
+__global__ void __launch_bounds__(256) read_probe_kernel(const uint4* __restrict__ p, uint64_t n16, uint32_t* sink) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    uint4 acc = make_uint4(0u, 0u, 0u, 0u);
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
+        acc.x ^= a.x ^ b.x ^ c.x ^ d.x; acc.y ^= a.y ^ b.y ^ c.y ^ d.y;
+        acc.z ^= a.z ^ b.z ^ c.z ^ d.z; acc.w ^= a.w ^ b.w ^ c.w ^ d.w;
+    }
+    for (; i < n16; i += stride) { const uint4 a = p[i]; acc.x ^= a.x; acc.y ^= a.y; acc.z ^= a.z; acc.w ^= a.w; }
+    if ((acc.x & acc.y & acc.z & acc.w) == 0xFFFFFFFFu && (acc.x ^ acc.y) == 0x12345678u) *sink = acc.x;
+}
+
+void launch_read_probe(hipStream_t s, const void* p, uint64_t bytes, uint32_t* sink) {
+    const uint64_t n16 = bytes / 16;
+    if (n16 == 0) return;
+    uint64_t blocks = (n16 + 255) / 256;
+    if (blocks > 256ull * 32) blocks = 256ull * 32;          // 32 workgroups per CU: a persistent grid-stride sweep
+    hipLaunchKernelGGL(read_probe_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const uint4*)p, n16, sink);
+}
+
+// ------------------------------------------------------------------------------------------
 // First voxel layer (SIA:1024-1046): a voxel that is not background and has a background voxel among
 // its six face neighbours keeps its label, every other tissue voxel becomes 0, background becomes 1
 // (keep_background) or 0 -- `image * (dilate6(image == bg) - (image == bg)) + (image == bg)`, one stencil pass.

@@ -730,6 +730,32 @@ TA_API int ta_timing(ta_ctx* c, double* ms_sweep, double* ms_adjacency, double* 
     return TA_OK;
 }
 
+TA_API int ta_read_probe(ta_ctx* c, const void* dev_ptr, uint64_t bytes, int repeats, double* ms_best) {
+    if (!c || !dev_ptr || !ms_best) return fail(TA_EINVAL, "NULL argument");
+    if (((uintptr_t)dev_ptr & 15) || bytes < 16) return fail(TA_EINVAL, "the probe needs a 16-byte aligned buffer of at least 16 bytes");
+    if (repeats < 1) repeats = 1;
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    double best = -1.0;
+    for (int r = 0; r < repeats + 1 && e == hipSuccess; ++r) {            // the first launch is a warm-up
+        e = hipEventRecord(e0, c->stream);
+        if (e == hipSuccess) { ta::launch_read_probe(c->stream, dev_ptr, bytes, maxlab_dev(c)); e = hipGetLastError(); }
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e == hipSuccess && r > 0 && (best < 0 || ms < best)) best = ms;
+    }
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    if (e != hipSuccess) return fail(TA_EHIP, "read probe: %s", hipGetErrorString(e));
+    *ms_best = best;
+    return TA_OK;
+}
+
 TA_API int ta_debug_counters(ta_ctx* c, uint32_t out[16]) {
     if (!c || !out) return fail(TA_EINVAL, "NULL argument");
     if (!c->extracted) return fail(TA_EINVAL, "no extraction has been run on this context");

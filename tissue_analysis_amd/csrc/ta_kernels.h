@@ -22,6 +22,7 @@ void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const ui
 void launch_relabel(hipStream_t s, void* vol, int itemsize, uint64_t n, const uint32_t* lut, uint32_t lut_len);
 void launch_map(hipStream_t s, const void* vol, int itemsize, void* out, int out_itemsize, uint64_t n,
                 const void* lut, uint32_t lut_len, uint64_t fill);
+void launch_read_probe(hipStream_t s, const void* p, uint64_t bytes, uint32_t* sink);
 void launch_first_layer(hipStream_t s, const void* vol, int itemsize, void* out, int64_t n0, int64_t n1, int64_t n2,
                         uint32_t background, int keep_background);
 uint64_t wall_chunks(int64_t n0, int64_t n1, int64_t n2);
