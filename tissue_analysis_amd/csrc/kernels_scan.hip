@@ -29,6 +29,9 @@
 
 namespace ta {
 
+#ifndef TA_XCD_CHUNK
+#define TA_XCD_CHUNK 4   // consecutive tiles given to one XCD (0 = plain order); 4 = one row of tiles of a 1024-wide volume
+#endif
 #ifndef TA_FCAP
 #define TA_FCAP 256
 #endif
@@ -704,6 +707,20 @@ __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanS
     if (!ADJ) hot_row_init(A, tid, wg);
 
     uint32_t t = blockIdx.x, tc, tb, band;
+#if TA_XCD_CHUNK > 0
+    // Workgroups are dealt round-robin over the 8 XCDs (speed only, never correctness: placement is not promised).
+    // Give each XCD CHUNKS of consecutive tiles -- neighbours along axes 2 and 1 -- so that the halo row a tile reads is
+    // the row its neighbour on the same XCD reads at about the same time (one HBM fetch, one L2), while chunks stay
+    // small enough that tissue and background tiles still spread evenly over the XCDs.
+    if (!EDGE) {
+        constexpr uint32_t G = TA_XCD_CHUNK;
+        const uint32_t full = (gridDim.x / (8u * G)) * (8u * G);
+        if (t < full) {
+            const uint32_t xcd = t % 8u, k = t / 8u;
+            t = ((k / G) * 8u + xcd) * G + (k % G);
+        }
+    }
+#endif
     if (!EDGE) {
         tc = t % sp.fc; t /= sp.fc; tb = t % sp.fb; band = t / sp.fb;
     } else {
