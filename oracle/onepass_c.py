@@ -9,7 +9,8 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _SRC = os.path.join(_HERE, "onepass_c.c")
-_LIB = os.path.join(_HERE, "_build", "libonepass_oracle.so")
+_LIB = os.environ.get("ONEPASS_ORACLE_LIB") or os.path.join(_HERE, "_build", "libonepass_oracle.so")
+_ASAN_LIB = os.path.join(_HERE, "_build", "libonepass_oracle_asan.so")
 _lib = None
 
 
@@ -21,6 +22,18 @@ def build(force=False):
     os.makedirs(os.path.dirname(_LIB), exist_ok=True)
     subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", _LIB, _SRC])
     return _LIB
+
+
+def build_sanitized(clang, force=False):
+    """clang -fsanitize=address,undefined build of the same file (tests/test_sanitized_host.py loads it through
+    ONEPASS_ORACLE_LIB in a child process that preloads the sanitizer runtime)."""
+    if (not force and os.path.exists(_ASAN_LIB)
+            and os.path.getmtime(_ASAN_LIB) >= os.path.getmtime(_SRC)):
+        return _ASAN_LIB
+    os.makedirs(os.path.dirname(_ASAN_LIB), exist_ok=True)
+    subprocess.check_call([clang, "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined",
+                           "-shared-libsan", "-shared", "-fPIC", "-o", _ASAN_LIB, _SRC])
+    return _ASAN_LIB
 
 
 def _load():

@@ -110,8 +110,10 @@ def build(force=False, save_temps=False, verbose=False):
             print(out)
     if failed:
         raise RuntimeError("hipcc compilation failed")
-    if procs and any(src == "kernels_scan.hip" for src, _ in procs):
+    stamp = os.path.join(OBJDIR, "kernels_scan.check.ok")       # (a failed check must not be skipped by the next call)
+    if _stale(stamp, [os.path.join(OBJDIR, "kernels_scan.o")]):
         _check_pinned(hipcc, verbose)
+        open(stamp, "w").write("ok\n")
     if force or procs or _stale(LIB, objs):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         if verbose:
@@ -120,5 +122,49 @@ def build(force=False, save_temps=False, verbose=False):
     return LIB
 
 
+ASAN_DIR = os.path.join(OBJDIR, "asan")
+ASAN_LIB = os.path.join(ASAN_DIR, "libtissue_scan_asan.so")
+
+
+def sanitizer_runtime():
+    """Path of the AddressSanitizer runtime hipcc's clang links with -shared-libsan (to LD_PRELOAD under python)."""
+    clang = os.path.join(os.path.dirname(os.path.realpath(_hipcc())), "..", "lib", "llvm", "bin", "clang++")
+    if not os.path.exists(clang):
+        clang = "/opt/rocm/lib/llvm/bin/clang++"
+    return subprocess.check_output([clang, "-print-file-name=libclang_rt.asan-x86_64.so"]).decode().strip()
+
+
+def build_sanitized(force=False, verbose=False):
+    """HOST side of the same three sources under -fsanitize=address,undefined (the device side cannot be
+    instrumented on this pool and is compiled as usual): the library the CPU suite loads to walk the C ABI's
+    argument checks and failure paths.  Never the product build."""
+    hipcc = _hipcc()
+    os.makedirs(ASAN_DIR, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    flags = [f for f in FLAGS if f != "-O3"] + ["-O1", "-g", "-fno-omit-frame-pointer",
+                                                "-fsanitize=address,undefined", "-Wno-option-ignored"]
+    procs, objs = [], []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(ASAN_DIR, src.replace(".hip", ".o"))
+        objs.append(o)
+        if force or _stale(o, [s] + hdrs):
+            cmd = [hipcc] + flags + ["-c", s, "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ASAN_DIR)))
+    for src, p in procs:
+        out = p.communicate()[0].decode(errors="replace")
+        if p.returncode != 0:
+            raise RuntimeError("hipcc (sanitized) failed on %s:\n%s" % (src, out))
+    if force or procs or _stale(ASAN_LIB, objs):
+        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-fsanitize=address,undefined",
+                               "-shared-libsan", "-o", ASAN_LIB] + objs)
+    return ASAN_LIB
+
+
 if __name__ == "__main__":
+    if "--asan" in sys.argv:
+        print(build_sanitized(force="--force" in sys.argv, verbose=True))
+        sys.exit(0)
     print(build(force="--force" in sys.argv, save_temps="--save-temps" in sys.argv, verbose=True))
