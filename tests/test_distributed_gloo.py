@@ -81,3 +81,39 @@ def test_device_layout_roundtrip():
     back = tad.from_device_layout(*tad.to_device_layout(r))
     for k in ("count", "bbox", "sum1", "sum2"):
         assert np.array_equal(back[k], r[k]), k
+
+
+def _halo_worker(rank, world, port, dims, dtype_name, out_q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tissue_analysis_amd import distributed as tad, synth
+        vol = synth.voronoi_labels(dims, 12, 5, np.dtype(dtype_name))
+        lo, hi = tad.slab_range(dims[0], world, rank)
+        signed = {"uint16": np.int16, "uint32": np.int32}[dtype_name]
+        owned = torch.from_numpy(vol[lo:hi].view(signed).copy())       # this rank holds ONLY its own planes
+        buf, halo = tad.attach_low_halo(owned)
+        want = vol[lo - (1 if rank else 0):hi].view(signed)
+        ok = bool(halo) == (rank > 0) and tuple(buf.shape) == want.shape and np.array_equal(buf.numpy(), want)
+        # a second hand-off into the same buffer (a time series re-using its slab buffers) changes nothing
+        tad.exchange_low_halo(buf)
+        ok = ok and np.array_equal(buf.numpy(), want)
+        out_q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims,dtype_name", [(2, (9, 6, 10), "uint16"), (3, (10, 5, 7), "uint32")])
+def test_halo_plane_arrives_from_the_neighbouring_rank(world, dims, dtype_name):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 27500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_halo_worker, args=(r, world, port, dims, dtype_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(r[0] for r in results) == list(range(world)) and all(r[1] for r in results), results

@@ -80,6 +80,58 @@ def test_two_ranks_on_one_gpu_match_unsharded(dims, n_cells, dtype_name, capacit
     assert all(r[1] for r in results), results
 
 
+def _handoff_worker(rank, world, port, dims, n_cells, seed, dtype_name, q):
+    """Each rank generates ONLY its own planes in device memory; plane lo-1 comes out of the neighbouring rank's
+    memory (attach_low_halo) -- no generator, no upload delivers it."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import onepass_c
+        from tissue_analysis_amd import _capi, device as dev, distributed as tad, synth
+        dtype = np.dtype(dtype_name)
+        ctx = dev.torch_context(0)
+        lo, hi = tad.slab_range(dims[0], world, rank)
+        owned, max_label = dev.synth_slab(ctx, dims, dtype, n_cells, seed, lo, hi, device=0)
+        torch.cuda.synchronize()
+        vol, halo = tad.attach_low_halo(owned, dist.group.WORLD)
+        whole = synth.voronoi_labels(dims, n_cells, seed, dtype)
+        signed = {"uint16": np.int16, "uint32": np.int32}[dtype_name]
+        bad = []
+        if bool(halo) != (rank > 0) or not np.array_equal(vol.cpu().numpy(), whole[lo - int(halo):hi].view(signed)):
+            bad.append("slab buffer")
+        job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=lo, has_low_halo=halo, max_label=max_label,
+                          features=_capi.F_ALL, group=dist.group.WORLD, device=0)
+        job.step()
+        got = job.result_arrays()
+        want = onepass_c.extract(whole, max_label=max_label)
+        bad += [k for k in ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces")
+                if not (got[k].shape == want[k].shape and np.array_equal(got[k], want[k]))]
+        q.put((rank, not bad, bad))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("dims,n_cells,dtype_name", [((37, 40, 264), 50, "uint32"), ((21, 24, 520), 30, "uint16")])
+def test_halo_handed_over_between_device_resident_slabs(dims, n_cells, dtype_name):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 28800 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_handoff_worker, args=(r, world, port, dims, n_cells, 67, dtype_name, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in results), results
+
+
 def _nccl_worker(rank, world, port, dims, n_cells, seed, q):
     """World size 1 over RCCL: the same SlabJob code path as a multi-GPU run (all-reduce, packed all-gather, merge of the
     gathered blocks), with torch.distributed's nccl backend on the one GPU of this box."""
@@ -96,6 +148,8 @@ def _nccl_worker(rank, world, port, dims, n_cells, seed, q):
         dtype = np.dtype("uint32")
         ctx = dev.torch_context(0)
         vol, max_label = dev.synth_slab(ctx, dims, dtype, n_cells, seed, 0, dims[0], device=0)
+        vol, halo = tad.attach_low_halo(vol, dist.group.WORLD)          # world 1: nothing to fetch
+        assert halo is False
         job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=0, has_low_halo=False, max_label=max_label,
                           features=_capi.F_ALL, group=dist.group.WORLD, device=0)
         for _ in range(3):

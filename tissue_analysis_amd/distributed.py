@@ -8,7 +8,8 @@ Every per-label quantity is a commutative reduction of exact integers, so the ex
   pairs                 all-gather of each rank's unique (key, faces[3]) list, then a hash merge
                         (the same pair shows up on two ranks when a wall crosses a slab boundary).
 A face is owned by the slab that owns its higher voxel along axis 0, so each slab carries ONE halo
-plane on its low side and no face is counted twice.
+plane on its low side and no face is counted twice.  A rank whose slab arrived without that plane gets
+it from its neighbour's memory: exchange_low_halo / attach_low_halo (isend/irecv of one plane).
 """
 from __future__ import annotations
 
@@ -79,6 +80,63 @@ def allgather_pairs(keys, faces, group=None):
     dist.all_gather_into_tensor(kall, kpad, group=group)
     dist.all_gather_into_tensor(fall, fpad, group=group)
     return kall, fall, max(m, 1)
+
+
+# ------------------------------------------------------------------ halo hand-off between neighbours
+def _plane_bytes(t):
+    """A contiguous plane (or stack of planes) as a flat uint8 tensor: what travels is bytes, whatever the label dtype."""
+    import torch
+    return t.contiguous().view(-1).view(torch.uint8)
+
+
+def exchange_low_halo(buf, group=None):
+    """SURVEY.md §8e, "a single P2P copy from the neighbour GPU": every rank but the last SENDS its last owned plane
+    (`buf[-1]`) to rank+1, every rank but the first RECEIVES plane lo-1 into `buf[0]` -- the spare low plane of its slab
+    buffer.  COLLECTIVE over `group`.  With backend "nccl" (RCCL) the planes go device to device over xGMI on the
+    current stream; gloo cannot move device tensors point to point, so there (CPU tests, two ranks sharing one GPU) the
+    plane is staged through the host.  `buf` is [planes (+1 on ranks > 0), n1, n2], device or CPU tensor."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world == 1:
+        return buf
+    if buf.shape[0] < (2 if rank > 0 else 1):
+        raise ValueError("every rank must own at least one plane of axis 0 (rank %d holds none)" % rank)
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    staged = buf.is_cuda and dist.get_backend(group) != "nccl"
+    send = recv = None
+    ops = []
+    if rank + 1 < world:
+        send = _plane_bytes(buf[-1])
+        if staged:
+            send = send.cpu()
+        ops.append(dist.P2POp(dist.isend, send, peer(rank + 1), group))
+    if rank > 0:
+        recv = torch.empty_like(_plane_bytes(buf[0]), device="cpu" if staged else buf.device)
+        ops.append(dist.P2POp(dist.irecv, recv, peer(rank - 1), group))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+    if recv is not None:
+        _plane_bytes(buf[0]).copy_(recv)          # (buf[0] is contiguous: the view aliases the plane)
+    return buf
+
+
+def attach_low_halo(owned, group=None):
+    """For a rank that holds ONLY its own planes [lo, hi) in device memory: a slab buffer with one spare low plane
+    (ranks > 0), the owned planes copied behind it, and plane lo-1 fetched from the neighbour (exchange_low_halo).
+    Returns (buffer, has_low_halo) -- the arguments SlabJob takes.  COLLECTIVE over `group`."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    if world == 1 or rank == 0:
+        buf, halo = owned.contiguous(), False
+    else:
+        buf = torch.empty((owned.shape[0] + 1,) + tuple(owned.shape[1:]), dtype=owned.dtype, device=owned.device)
+        buf[1:].copy_(owned)
+        halo = True
+    if world > 1:
+        exchange_low_halo(buf, group)
+    return buf, halo
 
 
 class SlabJob(object):
