@@ -203,9 +203,18 @@ TA_API int ta_wall_voxels_get(ta_ctx* ctx, uint32_t* lo, uint32_t* hi, int32_t* 
  * travel in the status word, so every rank reaches the same verdict: the next result getter
  * (ta_adjacency_size / _get / _device, ta_get_labels) returns TA_ECAPACITY when some block or
  * table was too small -- raise the capacity (or TA_OPT_PAIR_SLOTS) on every rank and redo the
- * step -- and TA_ERANGE when any rank saw a label above max_label. */
+ * step -- and TA_ERANGE when any rank saw a label above max_label.
+ *
+ * ta_adjacency_pack_shared is the cheaper pack for slabs: call it AFTER the bound per-label boxes were reduced over
+ * all ranks.  A label whose global axis-0 extent lies inside this slab's planes [lo, hi - 2] exists on no other rank
+ * (nor in its halo), so a pair with such a label is final here and stays (it is put back into this context's table);
+ * only the remaining pairs -- those a slab face can split -- are written to the block.  After
+ * ta_adjacency_merge_blocks the context then holds its PRIVATE pairs plus ALL ranks' travelling pairs merged; the
+ * global list is the union over ranks (private lists are disjoint, the merged part is the same everywhere).  Without
+ * TA_F_BBOX in the feature mask no label is exclusive and the call packs everything, like ta_adjacency_pack. */
 #define TA_EXCHANGE_WORDS(capacity_pairs) (2 + 4 * (int64_t)(capacity_pairs))
 TA_API int ta_adjacency_pack(ta_ctx* ctx, void* block_dev, int64_t capacity_pairs);
+TA_API int ta_adjacency_pack_shared(ta_ctx* ctx, void* block_dev, int64_t capacity_pairs);
 TA_API int ta_adjacency_merge_blocks(ta_ctx* ctx, const void* blocks_dev, int nblocks, int64_t capacity_pairs);
 
 /* Synthetic workload generator, bit-identical to tissue_analysis_amd/synth.py:

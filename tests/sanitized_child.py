@@ -65,6 +65,7 @@ def walk_c_abi():
         "ta_adjacency_export": (None, buf, buf, 4),
         "ta_adjacency_merge": (None, buf, buf, 4),
         "ta_adjacency_pack": (None, buf, 4),
+        "ta_adjacency_pack_shared": (None, buf, 4),
         "ta_adjacency_merge_blocks": (None, buf, 1, 4),
         "ta_synth_voronoi": (None, buf, 4, dims, 0, 4, buf, None, None),
         "ta_device_malloc": (None, 64, ctypes.byref(vp)),

@@ -117,3 +117,38 @@ def test_halo_plane_arrives_from_the_neighbouring_rank(world, dims, dtype_name):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert sorted(r[0] for r in results) == list(range(world)) and all(r[1] for r in results), results
+
+
+@pytest.mark.parametrize("world,dims,n_cells,scatter", [(2, (21, 16, 24), 14, 0), (3, (24, 12, 20), 30, 0), (4, (32, 10, 12), 40, 25)])
+def test_only_pairs_a_slab_face_can_split_need_to_travel(world, dims, n_cells, scatter):
+    """The rule of ta_adjacency_pack_shared, on the CPU: with the GLOBAL boxes, pairs that hold a slab-exclusive label are
+    final on their rank (and appear on no other), the rest merged over ranks completes the unsharded list -- also when
+    labels come in several pieces (scattered voxels of existing labels)."""
+    from oracle import onepass
+    from tissue_analysis_amd import distributed as tad, synth
+    vol = synth.voronoi_labels(dims, n_cells, 77, np.uint16)
+    rng = np.random.default_rng(5)
+    for _ in range(scatter):                                     # disconnected pieces of labels, anywhere
+        vol[tuple(rng.integers(0, d) for d in dims)] = rng.integers(1, int(vol.max()) + 1)
+    whole = onepass.extract(vol)
+    L = whole["max_label"]
+    _, gboxes = tad.to_device_layout(whole)
+    private_all, travelling = {}, {}
+    for rank in range(world):
+        lo, hi = tad.slab_range(dims[0], world, rank)
+        halo = 1 if lo > 0 else 0
+        part = onepass.extract(vol[lo - halo:hi], max_label=L, origin=(lo - halo, 0, 0), own_first_plane=not halo)
+        excl = tad.slab_exclusive(gboxes, lo, hi)
+        for a, b, f in zip(part["pair_lo"].tolist(), part["pair_hi"].tolist(), part["pair_faces"]):
+            if excl[a] or excl[b]:
+                assert (a, b) not in private_all                 # private lists are disjoint
+                private_all[(a, b)] = f.copy()
+            else:
+                travelling[(a, b)] = travelling.get((a, b), 0) + f
+    assert not set(private_all) & set(travelling)
+    merged = dict(private_all)
+    merged.update(travelling)
+    want = dict(((a, b), f) for a, b, f in zip(whole["pair_lo"].tolist(), whole["pair_hi"].tolist(), whole["pair_faces"]))
+    assert sorted(merged) == sorted(want)
+    assert all(np.array_equal(merged[k], want[k]) for k in want)
+    assert len(travelling) < len(want)                           # (something did stay at home)

@@ -30,7 +30,7 @@ SYMBOLS = (
     "ta_extract", "ta_get_labels",
     "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_read_probe", "ta_debug_counters", "ta_bind_accumulators",
     "ta_accumulators_device", "ta_accumulators_reduced", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge",
-    "ta_adjacency_pack", "ta_adjacency_merge_blocks", "ta_synth_voronoi",
+    "ta_adjacency_pack", "ta_adjacency_pack_shared", "ta_adjacency_merge_blocks", "ta_synth_voronoi",
     "ta_device_malloc", "ta_device_free", "ta_memcpy_d2h", "ta_memcpy_h2d",
 )
 
@@ -95,6 +95,7 @@ def load():
         "ta_adjacency_export": (ci, [vp, vp, vp, i64]),
         "ta_adjacency_merge": (ci, [vp, vp, vp, i64]),
         "ta_adjacency_pack": (ci, [vp, vp, i64]),
+        "ta_adjacency_pack_shared": (ci, [vp, vp, i64]),
         "ta_adjacency_merge_blocks": (ci, [vp, vp, ci, i64]),
         "ta_synth_voronoi": (ci, [vp, vp, ci, P(i64), i64, i64, vp, P(ctypes.c_int32), vp]),
         "ta_device_malloc": (ci, [vp, u64, P(vp)]),
@@ -351,6 +352,10 @@ class Context(object):
     def adjacency_pack(self, block_ptr, capacity):
         """Enqueue: write this rank's exchange block (exchange_words(capacity) uint64 words)."""
         _check(self._lib.ta_adjacency_pack(self._h, ctypes.c_void_p(int(block_ptr)), int(capacity)))
+
+    def adjacency_pack_shared(self, block_ptr, capacity):
+        """Enqueue: keep the pairs no other rank can hold (needs the REDUCED boxes), pack the rest."""
+        _check(self._lib.ta_adjacency_pack_shared(self._h, ctypes.c_void_p(int(block_ptr)), int(capacity)))
 
     def adjacency_merge_blocks(self, blocks_ptr, nblocks, capacity):
         """Enqueue: rebuild the adjacency from all ranks' gathered exchange blocks."""

@@ -106,7 +106,7 @@ __global__ void __launch_bounds__(256) max_label_kernel(const T* vol, uint64_t n
 }
 
 void launch_max_label(hipStream_t s, const void* vol, int itemsize, uint64_t nvox, uint32_t* out_dev) {
-    hipMemsetAsync(out_dev, 0, sizeof(uint32_t), s);
+    (void)hipMemsetAsync(out_dev, 0, sizeof(uint32_t), s);
     if (nvox == 0) return;
     uint64_t blocks = (nvox / (16 / itemsize) + 255) / 256;
     if (blocks < 1) blocks = 1;
@@ -225,6 +225,61 @@ void launch_pairs_pack(hipStream_t s, const uint64_t* keys, const uint64_t* face
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(pairs_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, keys, faces, cursor, flags,
                        block, cap);
+}
+
+// Slab-exclusive labels: with the per-label boxes already reduced over all ranks, a label whose axis-0 extent lies inside
+// [lo, hi - 2] can touch no other rank's planes nor its halo (the next rank's halo is plane hi - 1).  A pair with such a
+// label is final on this rank: it goes straight back into the (clean) table.  Only the other pairs -- the ones a wall
+// crossing a slab face can split -- travel.  A label without a box (no TA_F_BBOX) is never exclusive: everything travels.
+__device__ __forceinline__ bool slab_exclusive(const int32_t* boxes, uint32_t label, uint32_t max_label, int64_t lo, int64_t hi) {
+    if (label > max_label) return false;
+    const int32_t mn = boxes[(uint64_t)label * NBOX + 0], negmx = boxes[(uint64_t)label * NBOX + 3];
+    return mn != INT32_MAX && (int64_t)mn >= lo && -(int64_t)negmx <= hi - 2;
+}
+
+__global__ void __launch_bounds__(256) pairs_pack_shared_kernel(PairTable pt, const uint64_t* keys, const uint64_t* faces,
+                                                                const uint32_t* cursor, uint32_t* flags,
+                                                                const int32_t* boxes, uint32_t max_label, int64_t lo,
+                                                                int64_t hi, uint64_t* block, uint64_t cap) {
+    const uint64_t n = *cursor;
+    uint64_t* bk = block + XHDR;
+    uint64_t* bf = block + XHDR + cap;
+    if (blockIdx.x == 0 && threadIdx.x == 0)        // block[0] (the count) was zeroed on the stream before this launch
+        block[1] = (flags[FLAG_RANGE] ? XSTATUS_RANGE : 0) | (flags[FLAG_PAIR_OVERFLOW] ? XSTATUS_PAIR_OVERFLOW : 0);
+    const int lane = threadIdx.x & 63;
+    const uint64_t nround = (n + 63) & ~63ull;      // whole waves stay in the loop (ballot below)
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nround;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const bool live = i < n;
+        const uint64_t k = live ? keys[i] : EMPTY_KEY;
+        const uint32_t a = (uint32_t)(k >> 32), b = (uint32_t)k;
+        const bool valid = live && k != EMPTY_KEY;
+        const bool travels = valid && !slab_exclusive(boxes, a, max_label, lo, hi) && !slab_exclusive(boxes, b, max_label, lo, hi);
+        if (valid && !travels) pair_add_global(pt, a, b, faces[3 * i + 0], faces[3 * i + 1], faces[3 * i + 2], flags);
+        const uint64_t m = __ballot(travels);
+        if (m == 0ull) continue;
+        uint64_t base = 0;
+        if (lane == __ffsll((long long)m) - 1)
+            base = atomicAdd((unsigned long long*)&block[0], (unsigned long long)__popcll(m));
+        base = __shfl((long long)base, __ffsll((long long)m) - 1, 64);
+        if (travels) {
+            const uint64_t pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < cap) {
+                bk[pos] = k;
+                bf[3 * pos + 0] = faces[3 * i + 0]; bf[3 * pos + 1] = faces[3 * i + 1]; bf[3 * pos + 2] = faces[3 * i + 2];
+            }
+        }
+    }
+}
+
+void launch_pairs_pack_shared(hipStream_t s, const PairTable& pt, const uint64_t* keys, const uint64_t* faces,
+                              const uint32_t* cursor, uint32_t* flags, const int32_t* boxes, uint32_t max_label,
+                              int64_t lo, int64_t hi, uint64_t* block, uint64_t cap, uint64_t npairs_bound) {
+    uint64_t blocks = (npairs_bound + 255) / 256;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(pairs_pack_shared_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pt, keys, faces, cursor, flags,
+                       boxes, max_label, lo, hi, block, cap);
 }
 
 __global__ void __launch_bounds__(256) pairs_insert_blocks_kernel(PairTable pt, const uint64_t* blocks,

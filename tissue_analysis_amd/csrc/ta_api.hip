@@ -855,6 +855,25 @@ TA_API int ta_adjacency_pack(ta_ctx* c, void* block_dev, int64_t capacity_pairs)
     return TA_OK;
 }
 
+TA_API int ta_adjacency_pack_shared(ta_ctx* c, void* block_dev, int64_t capacity_pairs) {
+    if (!c || !block_dev) return fail(TA_EINVAL, "NULL argument");
+    if (capacity_pairs < 1) return fail(TA_EINVAL, "capacity_pairs must be >= 1");
+    if (!c->extracted || !(c->feature_mask & TA_F_ADJACENCY))
+        return fail(TA_EINVAL, "no extraction with adjacency has been run on this context");
+    if (c->exchanged) return fail(TA_EINVAL, "the adjacency of this extraction was already exchanged");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const int64_t lo = c->a_origin, hi = c->a_origin + (c->mdims[0] - c->first_owned);
+    TA_HIP(hipMemsetAsync(block_dev, 0, 8, c->stream));          // the block's pair count: the kernel's append cursor
+    // (the local list can hold no more pairs than the table has slots)
+    ta::launch_pairs_pack_shared(c->stream, pair_table(c), (const uint64_t*)c->out_keys.p, (const uint64_t*)c->out_faces.p,
+                                 cursor_dev(c), flags_dev(c), c->boxes, c->max_label, lo, hi, (uint64_t*)block_dev,
+                                 (uint64_t)capacity_pairs, 1ull << c->pair_log2);
+    TA_HIP(hipGetLastError());
+    c->table_clean = false;          // holds this rank's private pairs until ta_adjacency_merge_blocks collects
+    return TA_OK;
+}
+
 TA_API int ta_adjacency_merge_blocks(ta_ctx* c, const void* blocks_dev, int nblocks, int64_t capacity_pairs) {
     if (!c || !blocks_dev) return fail(TA_EINVAL, "NULL argument");
     if (nblocks < 1 || capacity_pairs < 1) return fail(TA_EINVAL, "nblocks and capacity_pairs must be >= 1");
@@ -870,6 +889,7 @@ TA_API int ta_adjacency_merge_blocks(ta_ctx* c, const void* blocks_dev, int nblo
     ta::launch_pairs_collect(c->stream, pt, (uint64_t*)c->out_keys.p, (uint64_t*)c->out_faces.p, cursor_dev(c));
     TA_HIP(hipMemcpyAsync(c->h_small, c->small.p, SMALL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost, c->stream));
     TA_HIP(hipGetLastError());
+    c->table_clean = true;
     c->exchanged = true;
     c->checked = false;
     c->host_pairs_ready = false;

@@ -16,6 +16,9 @@ void launch_pairs_insert(hipStream_t s, const PairTable& pt, const uint64_t* key
 void launch_pairs_clear(hipStream_t s, const PairTable& pt);
 void launch_pairs_pack(hipStream_t s, const uint64_t* keys, const uint64_t* faces, const uint32_t* cursor,
                        const uint32_t* flags, uint64_t* block, uint64_t cap);
+void launch_pairs_pack_shared(hipStream_t s, const PairTable& pt, const uint64_t* keys, const uint64_t* faces,
+                              const uint32_t* cursor, uint32_t* flags, const int32_t* boxes, uint32_t max_label,
+                              int64_t lo, int64_t hi, uint64_t* block, uint64_t cap, uint64_t npairs_bound);
 void launch_pairs_insert_blocks(hipStream_t s, const PairTable& pt, const uint64_t* blocks, int nblocks,
                                 uint64_t cap, uint32_t* flags);
 void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows);

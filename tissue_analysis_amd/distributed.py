@@ -139,6 +139,15 @@ def attach_low_halo(owned, group=None):
     return buf, halo
 
 
+def slab_exclusive(boxes, lo, hi):
+    """bool[L+1]: labels whose GLOBAL axis-0 extent lies inside planes [lo, hi - 2] of this rank's slab [lo, hi) -- no
+    other rank's planes, nor its halo, can hold them (the rule of ta_adjacency_pack_shared, on the reduced device-layout
+    boxes int32[L+1][6] = min0..2, -max0..2)."""
+    boxes = np.asarray(boxes)
+    mn, mx = boxes[:, 0].astype(np.int64), -boxes[:, 3].astype(np.int64)
+    return (boxes[:, 0] != INT32_MAX) & (mn >= lo) & (mx <= hi - 2)
+
+
 class SlabJob(object):
     """One rank's share of a slab-partitioned extraction, device-resident end to end.
 
@@ -146,8 +155,12 @@ class SlabJob(object):
     C-ABI context, then (world > 1) the RCCL reduce and the adjacency exchange.  After step() every
     rank holds the global per-label rows and `ctx.adjacency()` holds the global pairs.
 
+    Only the pairs a slab face can split travel (ta_adjacency_pack_shared, on the reduced boxes): after step() the
+    context of each rank holds its PRIVATE pairs plus all ranks' travelling pairs merged, and result_arrays() --
+    collective -- gathers the private lists once, when the global list is actually asked for.
+
     In steady state step() only ENQUEUES work (kernels and three collectives on one stream): the
-    adjacency travels in fixed-capacity exchange blocks (ta_adjacency_pack / _merge_blocks) whose
+    adjacency travels in fixed-capacity exchange blocks (ta_adjacency_pack_shared / _merge_blocks) whose
     capacity was agreed once, synchronously, on the first step.  Overflow and range flags ride in
     the block headers, so all ranks reach the same verdict; it is read when results are fetched
     (result_*), which re-sizes and redoes the step if a block or table was too small.
@@ -166,6 +179,7 @@ class SlabJob(object):
         if stream is not None:
             ctx.set_stream(stream.cuda_stream)
         self.has_low_halo = bool(has_low_halo)
+        self.a_origin = int(a_origin)           # global index of the first OWNED plane
         self.max_label, self.features = int(max_label), features
         dev = "cuda:%d" % device
         self.sums = torch.zeros((self.max_label + 1, 10), dtype=torch.int64, device=dev)
@@ -224,13 +238,30 @@ class SlabJob(object):
         if status not in (self._OK, self._CAPACITY):
             self._unverified = False
             self._raise_collectively(status, err)
-        if self._cap is None:
-            self._cap = max(1024, -(-(nmax + nmax // 4 + 1) // 1024) * 1024)
         again = smax != slots or status == self._CAPACITY
         if again:
             self.ctx.set_option(_capi.OPT_PAIR_SLOTS, max(smax, self.ctx.get_option(_capi.OPT_PAIR_SLOTS)))
             self.ctx.extract(self.features, self.max_label)
         return again
+
+    def _slab_planes(self):
+        lo = self.a_origin
+        return lo, lo + int(self.vol.shape[0]) - (1 if self.has_low_halo else 0)
+
+    def _agree_on_capacity(self):
+        """One-off and synchronous, after the boxes were reduced: the block capacity from the largest number of pairs
+        any rank has to send (a quarter more, in 1024s)."""
+        import torch.distributed as dist
+        torch = self._torch
+        plo, phi, _ = self.ctx.adjacency()
+        lo, hi = self._slab_planes()
+        excl = slab_exclusive(self.boxes.cpu().numpy(), lo, hi)
+        inside = (plo <= self.max_label) & (phi <= self.max_label)
+        travels = ~inside | ~(excl[np.minimum(plo, self.max_label)] | excl[np.minimum(phi, self.max_label)])
+        t = torch.tensor([int(travels.sum())], dtype=torch.int64, device=self.sums.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        nmax = int(t.item())
+        self._cap = max(1024, -(-(nmax + nmax // 4 + 1) // 1024) * 1024)
 
     def _exchange_buffers(self):
         import torch.distributed as dist
@@ -265,13 +296,16 @@ class SlabJob(object):
         if self.group is None:
             return
         adj = self._adjacency_wanted()
-        if adj and (self._cap is None or self._send is None):
+        first = adj and (self._cap is None or self._send is None)
+        if first:
             self._agree_on_sizes()
         allreduce_accumulators(self.sums, self.boxes, self.group)
         self.ctx.accumulators_reduced()          # from here on a local re-run would lose the other ranks' rows
         if adj:
+            if self._cap is None:
+                self._agree_on_capacity()
             world = self._exchange_buffers()
-            self.ctx.adjacency_pack(self._send.data_ptr(), self._cap)
+            self.ctx.adjacency_pack_shared(self._send.data_ptr(), self._cap)
             dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
             # With nccl (RCCL) the current stream -- which the context launches on -- already waits for
             # the collective; gloo moves device tensors through the host on its own streams.
@@ -310,6 +344,26 @@ class SlabJob(object):
         self._torch.cuda.synchronize()
         return self.sums[:, 0].cpu().numpy()
 
+    def _global_pairs(self, plo, phi, faces):
+        """COLLECTIVE: this context holds its private pairs + the merged travelling pairs (the same on every rank);
+        gather the other ranks' private lists and return the global list, sorted by (lo, hi)."""
+        import torch.distributed as dist
+        torch = self._torch
+        a0, a1 = self._slab_planes()
+        excl = slab_exclusive(self.boxes.cpu().numpy(), a0, a1)
+        private = excl[plo] | excl[phi]
+        on = self.sums.device if dist.get_backend(self.group) == "nccl" else "cpu"
+        keys = (plo.astype(np.int64) << 32) | phi.astype(np.int64)
+        kall, fall, _ = allgather_pairs(torch.from_numpy(keys[private]).to(on),
+                                        torch.from_numpy(faces[private].astype(np.int64)).to(on), self.group)
+        kall, fall = kall.cpu().numpy(), fall.cpu().numpy()
+        keep = kall != EMPTY_KEY
+        keys = np.concatenate([kall[keep], keys[~private]])
+        faces = np.concatenate([fall[keep].astype(np.uint64), faces[~private]])
+        order = np.argsort(keys, kind="stable")
+        keys = keys[order]
+        return (keys >> 32).astype(np.uint32), (keys & 0xFFFFFFFF).astype(np.uint32), faces[order]
+
     def result_arrays(self):
         """Global result in the host-getter layout (memory-axis order)."""
         self.finish()
@@ -319,6 +373,8 @@ class SlabJob(object):
         from . import _capi
         if _capi.feature_mask(self.features) & _capi.F_ADJACENCY:
             lo, hi, faces = self.ctx.adjacency()
+            if self._adjacency_wanted():
+                lo, hi, faces = self._global_pairs(lo, hi, faces)
         else:
             lo = hi = np.zeros(0, dtype=np.uint32)
             faces = np.zeros((0, 3), dtype=np.uint64)
