@@ -185,13 +185,14 @@ TA_API int ta_volume_first_layer(ta_ctx* ctx, uint32_t background, int keep_back
  * A voxel p of label l is a wall voxel of the pair (l, m) when one of its 18 neighbours (faces and
  * edges: scipy generate_binary_structure(3, 2), SIA:796-799) carries a label m != l; this is
  * (dil(mask_l) & mask_m) | (dil(mask_m) & mask_l) of wall_voxels_between_two_cells (SIA:759-806)
- * for every pair at once.  ta_wall_voxels_count runs the counting pass and returns the number of
- * (pair, voxel) records; ta_wall_voxels_get runs the emit pass and fills caller-allocated arrays of
- * that length: lo < hi labels and the voxel's coordinates in ARRAY-axis order, records ordered by the
+ * for every pair at once.  ta_wall_voxels_count runs the counting pass (one count per row strip, scanned
+ * on the device: the host reads back one number) and returns the number of (pair, voxel) records;
+ * ta_wall_voxels_get runs the emit pass and fills caller-allocated arrays of that length: the labels
+ * pairs[r] = (lo, hi), lo < hi, and the voxel's coordinates in ARRAY-axis order, records ordered by the
  * voxel's position in memory (for a C-ordered array: np.where order).  ms (optional) receives the
- * duration of the two kernels.  Not available on a slab with a halo plane. */
+ * duration of the kernels of both calls.  Not available on a slab with a halo plane. */
 TA_API int ta_wall_voxels_count(ta_ctx* ctx, int64_t* nrecords);
-TA_API int ta_wall_voxels_get(ta_ctx* ctx, uint32_t* lo, uint32_t* hi, int32_t* coords /* [n][3] */, double* ms);
+TA_API int ta_wall_voxels_get(ta_ctx* ctx, uint32_t* pairs /* [n][2] */, int32_t* coords /* [n][3] */, double* ms);
 
 /* ---- stream-ordered adjacency exchange (no host round trip) ------------------
  * One exchange block per rank, uint64 words, TA_EXCHANGE_WORDS(capacity) long:

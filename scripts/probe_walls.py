@@ -15,6 +15,6 @@ ctx.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, keep=vol)
 for it in range(2):
     lo, hi, coords, ms = ctx.wall_voxels()
     nvox = float(np.prod(dims))
-    print("%s %s: %d records (%.1f%% of voxels), count+emit kernels %.2f ms -> %.0f Mvoxel/s, %.0f GB/s of volume reads (2 passes) + record writes"
-          % (name, dims, lo.size, 100.0 * lo.size / nvox, ms, nvox / ms / 1e3,
-             (2 * nvox * dtype.itemsize + 16.0 * lo.size) / ms / 1e6), flush=True)
+    alg = nvox * dtype.itemsize + 20.0 * lo.size          # the volume once + 20-byte records (lo, hi, 3 coordinates)
+    print("%s %s: %d records (%.1f%% of voxels), count+scan+emit kernels %.3f ms -> %.0f Mvoxel/s, %.0f GB/s algorithmic = %.1f%% of 8 TB/s"
+          % (name, dims, lo.size, 100.0 * lo.size / nvox, ms, nvox / ms / 1e3, alg / ms / 1e6, alg / ms / 1e6 / 80.0), flush=True)

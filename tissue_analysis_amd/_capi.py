@@ -80,7 +80,7 @@ def load():
         "ta_volume_map": (ci, [vp, vp, u32, vp, ci, vp]),
         "ta_volume_first_layer": (ci, [vp, u32, ci, vp]),
         "ta_wall_voxels_count": (ci, [vp, P(i64)]),
-        "ta_wall_voxels_get": (ci, [vp, vp, vp, vp, P(ctypes.c_double)]),
+        "ta_wall_voxels_get": (ci, [vp, vp, vp, P(ctypes.c_double)]),
         "ta_extract": (ci, [vp, u32, u32]),
         "ta_get_labels": (ci, [vp, vp, vp, vp, vp]),
         "ta_adjacency_size": (ci, [vp, P(i64)]),
@@ -254,13 +254,11 @@ class Context(object):
         (array-axis order), ordered by the voxel's position in memory; plus the kernels' milliseconds."""
         n = ctypes.c_int64(0)
         _check(self._lib.ta_wall_voxels_count(self._h, ctypes.byref(n)))
-        lo = np.zeros(n.value, dtype=np.uint32)
-        hi = np.zeros(n.value, dtype=np.uint32)
-        coords = np.zeros((n.value, 3), dtype=np.int32)
+        pairs = np.empty((n.value, 2), dtype=np.uint32)
+        coords = np.empty((n.value, 3), dtype=np.int32)
         ms = ctypes.c_double(0.0)
-        _check(self._lib.ta_wall_voxels_get(self._h, lo.ctypes.data, hi.ctypes.data, coords.ctypes.data,
-                                            ctypes.byref(ms)))
-        return lo, hi, coords, ms.value
+        _check(self._lib.ta_wall_voxels_get(self._h, pairs.ctypes.data, coords.ctypes.data, ctypes.byref(ms)))
+        return pairs[:, 0], pairs[:, 1], coords, ms.value
 
     def set_volume_device(self, dev_ptr, itemsize, buf_dims, a0_origin=0, has_low_halo=False, keep=None):
         _check(self._lib.ta_volume_set_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(itemsize),

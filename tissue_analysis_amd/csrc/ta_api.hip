@@ -489,43 +489,58 @@ TA_API int ta_volume_first_layer(ta_ctx* c, uint32_t background, int keep_backgr
     return TA_OK;
 }
 
+namespace {
+// layout of ta_ctx::wall_counts: counts u32[cells] (padded to 8 bytes) | offsets u64[cells] | block sums u64[scan_blocks] | total u64
+// | lane counts u8[cells][64]
+struct WallBufs { uint32_t* counts; uint64_t* offsets; uint64_t* block_sums; uint64_t* total; uint8_t* lane_counts; uint64_t bytes; };
+WallBufs wall_bufs(void* base, const ta::WallPlan& p) {
+    WallBufs b;
+    const uint64_t counts_bytes = (p.cells * 4 + 7) & ~7ull;
+    b.counts = (uint32_t*)base;
+    b.offsets = (uint64_t*)((char*)base + counts_bytes);
+    b.block_sums = b.offsets + p.cells;
+    b.total = b.block_sums + p.scan_blocks;
+    b.lane_counts = (uint8_t*)(b.total + 1);
+    b.bytes = counts_bytes + (p.cells + p.scan_blocks + 1) * 8 + p.cells * 64;
+    return b;
+}
+}  // namespace
+
 TA_API int ta_wall_voxels_count(ta_ctx* c, int64_t* nrecords) {
     if (!c || !nrecords) return fail(TA_EINVAL, "NULL argument");
     if (!c->vol) return fail(TA_EINVAL, "no volume set");
     if (c->first_owned) return fail(TA_EINVAL, "wall voxels are not available on a slab that carries a halo plane");
     int rc = use_device(c);
     if (rc != TA_OK) return rc;
-    const uint64_t chunks = ta::wall_chunks(c->mdims[0], c->mdims[1], c->mdims[2]);
-    if ((rc = c->wall_counts.reserve(chunks * 8 + 8)) != TA_OK) return rc;
+    const ta::WallPlan plan = ta::wall_plan(c->mdims[0], c->mdims[1], c->mdims[2]);
+    if ((rc = c->wall_counts.reserve(wall_bufs(nullptr, plan).bytes)) != TA_OK) return rc;
+    const WallBufs wb = wall_bufs(c->wall_counts.p, plan);
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    std::vector<uint64_t> h;
-    try { h.assign(chunks + 1, 0); } catch (...) { return fail(TA_ENOMEM, "out of host memory"); }
+    uint64_t total = 0;
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
     if (e == hipSuccess) {
-        ta::launch_wall_count(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], (uint64_t*)c->wall_counts.p);
+        // count per (row, strip), scan on the device: the only thing the host needs before the emit pass is the total
+        ta::launch_wall_count(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], wb.counts, wb.lane_counts,
+                              wb.offsets, wb.block_sums, wb.total);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(h.data(), c->wall_counts.p, chunks * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(&total, wb.total, 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     float ms = 0.f;
     if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (e != hipSuccess) return fail(TA_EHIP, "wall voxel count: %s", hipGetErrorString(e));
-    uint64_t run = 0;                                        // exclusive scan of the chunk counts
-    for (uint64_t k = 0; k < chunks; ++k) { const uint64_t n = h[k]; h[k] = run; run += n; }
-    TA_HIP(hipMemcpyAsync(c->wall_counts.p, h.data(), chunks * 8, hipMemcpyHostToDevice, c->stream));
-    TA_HIP(hipStreamSynchronize(c->stream));
-    c->wall_records = (int64_t)run;
+    c->wall_records = (int64_t)total;
     c->wall_ms = ms;
     *nrecords = c->wall_records;
     return TA_OK;
 }
 
-TA_API int ta_wall_voxels_get(ta_ctx* c, uint32_t* lo, uint32_t* hi, int32_t* coords, double* ms_out) {
+TA_API int ta_wall_voxels_get(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_out) {
     if (!c) return fail(TA_EINVAL, "ctx is NULL");
     if (c->wall_records < 0) return fail(TA_EINVAL, "call ta_wall_voxels_count first");
     int rc = use_device(c);
@@ -533,40 +548,33 @@ TA_API int ta_wall_voxels_get(ta_ctx* c, uint32_t* lo, uint32_t* hi, int32_t* co
     const uint64_t n = (uint64_t)c->wall_records;
     if (ms_out) *ms_out = c->wall_ms;
     if (n == 0) return TA_OK;
-    if (!lo || !hi || !coords) return fail(TA_EINVAL, "NULL output array");
-    DevBuf dk, di;
-    if ((rc = dk.reserve(n * 8)) != TA_OK) return rc;
-    if ((rc = di.reserve(n * 8)) != TA_OK) { dk.release(); return rc; }
-    std::vector<uint64_t> hk, hi64;
-    try { hk.resize(n); hi64.resize(n); } catch (...) { dk.release(); di.release(); return fail(TA_ENOMEM, "out of host memory"); }
+    if (!pairs || !coords) return fail(TA_EINVAL, "NULL output array");
+    const ta::WallPlan plan = ta::wall_plan(c->mdims[0], c->mdims[1], c->mdims[2]);
+    const WallBufs wb = wall_bufs(c->wall_counts.p, plan);
+    DevBuf dpa, dco;
+    if ((rc = dpa.reserve(n * 8)) != TA_OK) return rc;
+    if ((rc = dco.reserve(n * 12)) != TA_OK) { dpa.release(); return rc; }
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
     if (e == hipSuccess) {
-        ta::launch_wall_emit(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2],
-                             (const uint64_t*)c->wall_counts.p, (uint64_t*)dk.p, (uint64_t*)di.p);
+        // records leave the kernel as (lo, hi) / coordinates in ARRAY-axis order: straight into the caller's arrays
+        ta::launch_wall_emit(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], wb.counts, wb.lane_counts,
+                             wb.offsets, (uint32_t*)dpa.p, (int32_t*)dco.p, c->perm);
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(hk.data(), dk.p, n * 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(hi64.data(), di.p, n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pairs, dpa.p, n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(coords, dco.p, n * 12, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     float ms = 0.f;
     if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    dk.release(); di.release();
+    dpa.release(); dco.release();
     if (e != hipSuccess) return fail(TA_EHIP, "wall voxels: %s", hipGetErrorString(e));
     if (ms_out) *ms_out = c->wall_ms + ms;
-    const int64_t n1 = c->mdims[1], n2 = c->mdims[2];
-    for (uint64_t r = 0; r < n; ++r) {
-        lo[r] = (uint32_t)(hk[r] >> 32);
-        hi[r] = (uint32_t)(hk[r] & 0xffffffffu);
-        const int64_t i = (int64_t)hi64[r], a = i / (n1 * n2), rem = i - a * n1 * n2;
-        const int64_t m[3] = {a, rem / n2, rem % n2};
-        for (int k = 0; k < 3; ++k) coords[3 * r + c->perm[k]] = (int32_t)m[k];
-    }
     return TA_OK;
 }
 

@@ -28,11 +28,17 @@ void launch_map(hipStream_t s, const void* vol, int itemsize, void* out, int out
 void launch_read_probe(hipStream_t s, const void* p, uint64_t bytes, uint32_t* sink);
 void launch_first_layer(hipStream_t s, const void* vol, int itemsize, void* out, int64_t n0, int64_t n1, int64_t n2,
                         uint32_t background, int keep_background);
-uint64_t wall_chunks(int64_t n0, int64_t n1, int64_t n2);
+
+// kernels_walls.hip -- wall voxels (count per (row, strip) + device scan, then emit in memory order)
+struct WallPlan { int32_t nstrips, rows_per_wave; uint64_t cells, scan_blocks, waves; };
+WallPlan wall_plan(int64_t n0, int64_t n1, int64_t n2);
 void launch_wall_count(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2,
-                       uint64_t* chunk_counts);
+                       uint32_t* counts, uint8_t* lane_counts, uint64_t* offsets, uint64_t* block_sums, uint64_t* total);
 void launch_wall_emit(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2,
-                      const uint64_t* chunk_offsets, uint64_t* out_keys, uint64_t* out_index);
+                      const uint32_t* counts, const uint8_t* lane_counts, const uint64_t* offsets, uint32_t* out_pairs,
+                      int32_t* out_coords, const int perm[3]);
+
+// kernels_basic.hip (continued)
 void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3], int64_t a_begin,
                   int64_t a_count, const int32_t* seeds_dev, const int32_t grid[3],
                   const int64_t* ell_dev);
