@@ -32,6 +32,10 @@ namespace ta {
 #ifndef TA_XCD_CHUNK
 #define TA_XCD_CHUNK 4   // consecutive tiles given to one XCD (0 = plain order); 4 = one row of tiles of a 1024-wide volume
 #endif
+// the hot (most common) label of the volume gets a private row per workgroup, also with adjacency
+#ifndef TA_HOT_ADJ
+#define TA_HOT_ADJ 1
+#endif
 #ifndef TA_FCAP
 #define TA_FCAP 256
 #endif
@@ -704,7 +708,7 @@ __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanS
         }
     }
     const uint32_t wg = wg0 + blockIdx.x;
-    if (!ADJ) hot_row_init(A, tid, wg);
+    if (TA_HOT_ADJ || !ADJ) hot_row_init(A, tid, wg);
 
     uint32_t t = blockIdx.x, tc, tb, band;
 #if TA_XCD_CHUNK > 0
@@ -744,8 +748,8 @@ __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanS
     //  rather than kept in scarce SGPRs across the sweep)
     const SweepArgs& Ac = *cold_args(kp);
     const uint32_t wg_ = reinterpret_cast<const uint32_t*>(&Ac + 1)[sizeof(ScanSplit) / 4] + blockIdx.x;     // wg0 + block
-    flush_tables<NW, ADJ, MOM2, !ADJ>(Ac, S, threadIdx.x, (uint64_t)S.frame[0], (uint64_t)S.frame[1], (uint64_t)S.frame[2],
-                                      ADJ ? 0u : hot_label_of<T>(Ac), wg_);
+    flush_tables<NW, ADJ, MOM2, (TA_HOT_ADJ || !ADJ)>(Ac, S, threadIdx.x, (uint64_t)S.frame[0], (uint64_t)S.frame[1], (uint64_t)S.frame[2],
+                                      (TA_HOT_ADJ || !ADJ) ? hot_label_of<T>(Ac) : 0u, wg_);
 }
 
 // (two entry points only because the VGPR budget is an attribute and must be a literal)

@@ -161,8 +161,7 @@ int run_extract(ta_ctx* c) {
     a.flags = flags_dev(c);
     uint64_t* hot_rows = nullptr;
     uint64_t nwg = 0;
-    const bool adj_wanted = c->feature_mask & TA_F_ADJACENCY;
-    if (c->impl == 0 && !adj_wanted) {           // the sweep without adjacency keeps a private row per workgroup for the hot label
+    if (c->impl == 0) {           // the sweep keeps a private row per workgroup for the hot label
         nwg = ta::sweep_grid_size(a, c->itemsize);
         int rc0 = c->hot_rows.reserve(nwg * ta::HOTW * 8);
         if (rc0 != TA_OK) return rc0;

@@ -118,8 +118,7 @@ __device__ __forceinline__ void hot_row_init(const SweepArgs& A, const int tid, 
 }
 __device__ __forceinline__ void hot_row_init(const SweepArgs& A, const int tid) { hot_row_init(A, tid, blockIdx.x); }
 
-// HOT = false compiles the hot-row path out (the fused adjacency kernels sit on the edge of their register
-// budget: any extra code, even here in the epilogue, tips their allocation from 1 into ~100 spilled registers).
+// HOT = false compiles the hot-row path out (the naive cross-check kernel's rows; the sweep uses it for every mask).
 template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS>
 __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const int tid, const uint64_t A0,
                                              const uint64_t B0, const uint64_t C0, const uint32_t hot,
