@@ -119,8 +119,9 @@ TA_API int ta_get_labels(ta_ctx* ctx, uint64_t* count, int32_t* bbox, uint64_t* 
 TA_API int ta_adjacency_size(ta_ctx* ctx, int64_t* npairs);
 TA_API int ta_adjacency_get(ta_ctx* ctx, uint32_t* lo, uint32_t* hi, uint64_t* faces);
 
-/* Timing of the last ta_extract (HIP events on the context stream): the sweep kernel alone,
- * the adjacency collection, the whole call; bytes_read = nvox * itemsize (algorithmic bytes). */
+/* Timing of the last ta_extract (HIP events on the context stream): the sweep kernel alone, what follows
+ * it (fold of the per-workgroup hot-label rows + adjacency collection), the whole call from the accumulator
+ * init on; bytes_read = nvox * itemsize (algorithmic bytes). */
 TA_API int ta_timing(ta_ctx* ctx, double* ms_sweep, double* ms_adjacency, double* ms_total,
               uint64_t* bytes_read);
 

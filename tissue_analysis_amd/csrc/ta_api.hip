@@ -178,8 +178,8 @@ int run_extract(ta_ctx* c) {
     TA_HIP(hipEventRecord(c->ev[1], c->stream));
     if (c->impl == 1) ta::launch_naive(c->stream, a, c->itemsize, c->feature_mask);
     else              ta::launch_scan(c->stream, a, c->itemsize, c->feature_mask);
+    TA_HIP(hipEventRecord(c->ev[2], c->stream));        // [1,2) = the sweep kernel alone (what the roofline is quoted on)
     if (hot_rows) ta::launch_hot_reduce(c->stream, a, c->itemsize, hot_rows, (uint32_t)nwg);
-    TA_HIP(hipEventRecord(c->ev[2], c->stream));
     if (adj)
         ta::launch_pairs_collect(c->stream, a.pairs, (uint64_t*)c->out_keys.p, (uint64_t*)c->out_faces.p,
                                  cursor_dev(c));
