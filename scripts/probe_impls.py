@@ -1,6 +1,6 @@
 """Time several sweep implementations on one resident volume, checking that they agree bit for bit.
 
-    python scripts/probe_impls.py [CONFIG] [--impl 0 6 ...] [--feat 0x1f 0x0f ...] [--iters K] [--no-ellipsoid]
+    python scripts/probe_impls.py [CONFIG] [--impl 0 1] [--feat 0x1f 0x0f ...] [--iters K] [--no-ellipsoid]
 """
 import argparse
 import time
@@ -12,7 +12,7 @@ from tissue_analysis_amd import _capi, device as dev, synth
 
 ap = argparse.ArgumentParser()
 ap.add_argument("config", nargs="?", default="C4")
-ap.add_argument("--impl", type=int, nargs="*", default=[0, 6])
+ap.add_argument("--impl", type=int, nargs="*", default=[0])       # 1 = the per-voxel-atomics cross-check kernel (slow)
 ap.add_argument("--feat", type=lambda s: int(s, 0), nargs="*", default=[0x1f])
 ap.add_argument("--tp", type=int, nargs="*", default=[0])
 ap.add_argument("--iters", type=int, default=5)
