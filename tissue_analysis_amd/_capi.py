@@ -58,6 +58,14 @@ def load():
         raise ImportError(
             "%s is missing: the HIP extension has not been built "
             "(run `python -m tissue_analysis_amd.build`); there is no CPU fallback" % LIB_PATH)
+    # PyTorch-ROCm ships its own copy of the HIP / HSA runtime; libtissue_scan.so is linked against /opt/rocm's.  Two
+    # runtimes in one process cannot both open the GPU ("No HIP GPUs are available" from whichever comes second) unless
+    # torch's is the one the loader sees first -- then this library binds to it too.  So when torch is installed, it is
+    # imported before the library is opened, whatever order the caller's imports have.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = ctypes.CDLL(LIB_PATH)
     vp, i64, u32, u64, ci = (ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint64,
                              ctypes.c_int)

@@ -791,7 +791,9 @@ uint64_t sweep_grid_size(const SweepArgs& a, int itemsize) {
     const ScanSplit sp = itemsize == 2 ? scan_split<8, 2>(a, 2) : scan_split<4, TA_RB32>(a, 4);
     return (uint64_t)sp.tiles_c * sp.tiles_b * sp.nbands;
 }
-int sweep_default_tile_planes() { return 32; }   // 64 planes start to overflow the 128-slot label table
+// measured on C4 (profiles/r02_ablations.txt): shorter tiles = more workgroups to balance over the CUs against more
+// table inits / flushes; 64 planes start to overflow the 128-slot label table
+int sweep_default_tile_planes(bool adjacency) { return adjacency ? 24 : 16; }
 int sweep_max_tile_planes() { return MAX_TILE_PLANES; }
 
 void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask) {

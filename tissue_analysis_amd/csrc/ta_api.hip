@@ -147,7 +147,7 @@ int run_extract(ta_ctx* c) {
     a.n0 = c->mdims[0]; a.n1 = c->mdims[1]; a.n2 = c->mdims[2];
     a.a_origin = c->a_origin;
     a.first_owned = c->first_owned;
-    a.tile_planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes();
+    a.tile_planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY);
     if (c->tile_planes <= 0) {
         // automatic: small volumes get shorter tiles until the launch has >= 2048 workgroups (8 per CU)
         while (a.tile_planes > 8 && ta::sweep_grid_size(a, c->itemsize) < 2048) a.tile_planes /= 2;
@@ -333,7 +333,7 @@ TA_API int ta_ctx_get_option(ta_ctx* c, int key, int64_t* value) {
     if (!c || !value) return fail(TA_EINVAL, "NULL argument");
     switch (key) {
         case TA_OPT_IMPL: *value = c->impl; return TA_OK;
-        case TA_OPT_TILE_PLANES: *value = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(); return TA_OK;
+        case TA_OPT_TILE_PLANES: *value = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY); return TA_OK;
         case TA_OPT_PAIR_SLOTS: *value = c->pkeys.p ? c->pair_log2 : c->opt_pair_log2; return TA_OK;
         default: return fail(TA_EINVAL, "unknown option key %d", key);
     }

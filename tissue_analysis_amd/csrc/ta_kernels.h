@@ -46,7 +46,7 @@ void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3],
 // kernels_scan.hip -- the sweep
 void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);
 uint64_t sweep_grid_size(const SweepArgs& a, int itemsize);   // workgroups of any of the sweep kernels
-int sweep_default_tile_planes();
+int sweep_default_tile_planes(bool adjacency);
 int sweep_max_tile_planes();
 
 }  // namespace ta
