@@ -194,6 +194,9 @@ TA_API int ta_volume_first_layer(ta_ctx* ctx, uint32_t background, int keep_back
  * duration of the kernels of both calls.  Not available on a slab with a halo plane. */
 TA_API int ta_wall_voxels_count(ta_ctx* ctx, int64_t* nrecords);
 TA_API int ta_wall_voxels_get(ta_ctx* ctx, uint32_t* pairs /* [n][2] */, int32_t* coords /* [n][3] */, double* ms);
+/* The same records GROUPED BY PAIR: sorted by (lo, hi) on the device (stable radix sort), the voxels of one pair still
+ * in memory order -- what wall_voxels_between_two_cells / _per_cell / _per_cells_pairs look up (SIA:759-880). */
+TA_API int ta_wall_voxels_get_by_pair(ta_ctx* ctx, uint32_t* pairs /* [n][2] */, int32_t* coords /* [n][3] */, double* ms);
 
 /* ---- stream-ordered adjacency exchange (no host round trip) ------------------
  * One exchange block per rank, uint64 words, TA_EXCHANGE_WORDS(capacity) long:

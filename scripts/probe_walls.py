@@ -12,7 +12,12 @@ if len(sys.argv) > 2:
 ctx = dev.torch_context(0)
 vol, max_label = dev.synth_slab(ctx, dims, dtype, c["n_cells"], c["seed"])
 ctx.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, keep=vol)
+import time
 for it in range(2):
+    t0 = time.perf_counter()
+    glo, ghi, gcoords, gms = ctx.wall_voxels(by_pair=True)
+    t1 = time.perf_counter()
+    print("grouped by pair on the device: kernels %.3f ms, call %.1f ms (records to the host included)" % (gms, (t1 - t0) * 1e3), flush=True)
     lo, hi, coords, ms = ctx.wall_voxels()
     nvox = float(np.prod(dims))
     alg = nvox * dtype.itemsize + 20.0 * lo.size          # the volume once + 20-byte records (lo, hi, 3 coordinates)

@@ -51,6 +51,7 @@ def walk_c_abi():
         "ta_volume_first_layer": (None, 1, 1, buf),
         "ta_wall_voxels_count": (None, ctypes.byref(i64)),
         "ta_wall_voxels_get": (None, buf, buf, ctypes.byref(dbl)),
+        "ta_wall_voxels_get_by_pair": (None, buf, buf, ctypes.byref(dbl)),
         "ta_extract": (None, 31, 10),
         "ta_get_labels": (None, buf, buf, buf, buf),
         "ta_adjacency_size": (None, ctypes.byref(i64)),

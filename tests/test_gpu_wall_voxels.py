@@ -97,3 +97,24 @@ def test_table_properties_on_a_larger_volume():
     walls = set(zip(lo.tolist(), hi.tolist()))
     assert faces <= walls
     assert t.ms is not None and t.ms > 0
+
+
+def test_records_grouped_on_the_device_equal_the_host_sort():
+    """ta_wall_voxels_get_by_pair (stable radix sort by pair on the device) against ta_wall_voxels_get + the stable host
+    sort WallTable used to do -- same keys, same coordinates, same order."""
+    from tissue_analysis_amd.extraction import ResidentVolume, WallTable
+    for vol in (voronoi((48, 40, 300), 60, 67, np.uint16), voronoi((31, 33, 70), 40, 68, np.uint32),
+                random_blocks((9, 11, 23), 12, 69, np.uint16)):
+        rv = ResidentVolume(vol)
+        try:
+            lo, hi, coords, _ = rv.ctx.wall_voxels()
+            want = WallTable(lo, hi, coords)
+            glo, ghi, gcoords, ms = rv.ctx.wall_voxels(by_pair=True)
+            got = WallTable(glo, ghi, gcoords, ms, grouped=True)
+            assert np.array_equal(got.key, want.key) and np.array_equal(got.coords, want.coords)
+            assert np.array_equal(got.pairs, want.pairs) and np.array_equal(got.start, want.start)
+            assert np.all(got.key[1:] >= got.key[:-1])
+            table = rv.wall_table()                  # the product path takes the grouped fetch for C-ordered images
+            assert np.array_equal(table.key, want.key) and np.array_equal(table.coords, want.coords)
+        finally:
+            rv.close()

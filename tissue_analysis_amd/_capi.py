@@ -26,7 +26,7 @@ SYMBOLS = (
     "ta_version", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_get_option", "ta_ctx_synchronize", "ta_volume_set",
     "ta_volume_set_device", "ta_volume_max_label", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
-    "ta_volume_first_layer", "ta_wall_voxels_count", "ta_wall_voxels_get",
+    "ta_volume_first_layer", "ta_wall_voxels_count", "ta_wall_voxels_get", "ta_wall_voxels_get_by_pair",
     "ta_extract", "ta_get_labels",
     "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_read_probe", "ta_debug_counters", "ta_bind_accumulators",
     "ta_accumulators_device", "ta_accumulators_reduced", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge",
@@ -89,6 +89,7 @@ def load():
         "ta_volume_first_layer": (ci, [vp, u32, ci, vp]),
         "ta_wall_voxels_count": (ci, [vp, P(i64)]),
         "ta_wall_voxels_get": (ci, [vp, vp, vp, P(ctypes.c_double)]),
+        "ta_wall_voxels_get_by_pair": (ci, [vp, vp, vp, P(ctypes.c_double)]),
         "ta_extract": (ci, [vp, u32, u32]),
         "ta_get_labels": (ci, [vp, vp, vp, vp, vp]),
         "ta_adjacency_size": (ci, [vp, P(i64)]),
@@ -257,15 +258,17 @@ class Context(object):
                                                ctypes.c_void_p(out.ctypes.data)))
         return out
 
-    def wall_voxels(self):
+    def wall_voxels(self, by_pair=False):
         """All (pair, wall voxel) records of the resident volume: lo u32[n], hi u32[n], coords i32[n,3]
-        (array-axis order), ordered by the voxel's position in memory; plus the kernels' milliseconds."""
+        (array-axis order), ordered by the voxel's position in memory -- or, with by_pair, grouped by (lo, hi) on the
+        device with each pair's voxels in memory order; plus the kernels' milliseconds."""
         n = ctypes.c_int64(0)
         _check(self._lib.ta_wall_voxels_count(self._h, ctypes.byref(n)))
         pairs = np.empty((n.value, 2), dtype=np.uint32)
         coords = np.empty((n.value, 3), dtype=np.int32)
         ms = ctypes.c_double(0.0)
-        _check(self._lib.ta_wall_voxels_get(self._h, pairs.ctypes.data, coords.ctypes.data, ctypes.byref(ms)))
+        fetch = self._lib.ta_wall_voxels_get_by_pair if by_pair else self._lib.ta_wall_voxels_get
+        _check(fetch(self._h, pairs.ctypes.data, coords.ctypes.data, ctypes.byref(ms)))
         return pairs[:, 0], pairs[:, 1], coords, ms.value
 
     def set_volume_device(self, dev_ptr, itemsize, buf_dims, a0_origin=0, has_low_halo=False, keep=None):

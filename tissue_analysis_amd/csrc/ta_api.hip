@@ -539,7 +539,8 @@ TA_API int ta_wall_voxels_count(ta_ctx* c, int64_t* nrecords) {
     return TA_OK;
 }
 
-TA_API int ta_wall_voxels_get(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_out) {
+namespace {
+int wall_voxels_fetch(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_out, bool by_pair) {
     if (!c) return fail(TA_EINVAL, "ctx is NULL");
     if (c->wall_records < 0) return fail(TA_EINVAL, "call ta_wall_voxels_count first");
     int rc = use_device(c);
@@ -548,11 +549,18 @@ TA_API int ta_wall_voxels_get(ta_ctx* c, uint32_t* pairs, int32_t* coords, doubl
     if (ms_out) *ms_out = c->wall_ms;
     if (n == 0) return TA_OK;
     if (!pairs || !coords) return fail(TA_EINVAL, "NULL output array");
+    if (by_pair && n >= (1ull << 32)) return fail(TA_EINVAL, "too many records (%llu) for the grouped fetch", (unsigned long long)n);
     const ta::WallPlan plan = ta::wall_plan(c->mdims[0], c->mdims[1], c->mdims[2]);
     const WallBufs wb = wall_bufs(c->wall_counts.p, plan);
-    DevBuf dpa, dco;
-    if ((rc = dpa.reserve(n * 8)) != TA_OK) return rc;
-    if ((rc = dco.reserve(n * 12)) != TA_OK) { dpa.release(); return rc; }
+    // one allocation: records in memory order | (grouped fetch) the same again grouped, sort keys / indices x 2, sort temp
+    const uint64_t temp_bytes = by_pair ? ta::wall_sort_temp_bytes(n) : 0;
+    const uint64_t rec = n * 8, co = (n * 12 + 15) & ~15ull, ix = (n * 4 + 15) & ~15ull;
+    DevBuf buf;
+    if ((rc = buf.reserve(by_pair ? 2 * rec + 2 * co + 2 * rec + 2 * ix + temp_bytes + 64 : rec + co)) != TA_OK) return rc;
+    char* p = (char*)buf.p;
+    uint32_t* dpa = (uint32_t*)p; p += rec;
+    int32_t* dco = (int32_t*)p; p += co;
+    uint32_t* gpa = dpa; int32_t* gco = dco;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
@@ -560,21 +568,40 @@ TA_API int ta_wall_voxels_get(ta_ctx* c, uint32_t* pairs, int32_t* coords, doubl
     if (e == hipSuccess) {
         // records leave the kernel as (lo, hi) / coordinates in ARRAY-axis order: straight into the caller's arrays
         ta::launch_wall_emit(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], wb.counts, wb.lane_counts,
-                             wb.offsets, (uint32_t*)dpa.p, (int32_t*)dco.p, c->perm);
+                             wb.offsets, dpa, dco, c->perm);
         e = hipGetLastError();
     }
+    if (e == hipSuccess && by_pair) {
+        gpa = (uint32_t*)p; p += rec;
+        gco = (int32_t*)p; p += co;
+        uint64_t* k0 = (uint64_t*)p; p += rec;
+        uint64_t* k1 = (uint64_t*)p; p += rec;
+        uint32_t* i0 = (uint32_t*)p; p += ix;
+        uint32_t* i1 = (uint32_t*)p; p += ix;
+        const int label_bits = c->itemsize == 2 ? 16 : 32;          // bits a label of this volume can occupy
+        e = ta::launch_wall_group_by_pair(c->stream, dpa, dco, n, k0, k1, i0, i1, p, temp_bytes, label_bits, gpa, gco);
+    }
     if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(pairs, dpa.p, n * 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(coords, dco.p, n * 12, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pairs, gpa, n * 8, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(coords, gco, n * 12, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     float ms = 0.f;
     if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
-    dpa.release(); dco.release();
+    buf.release();
     if (e != hipSuccess) return fail(TA_EHIP, "wall voxels: %s", hipGetErrorString(e));
     if (ms_out) *ms_out = c->wall_ms + ms;
     return TA_OK;
+}
+}  // namespace
+
+TA_API int ta_wall_voxels_get(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_out) {
+    return wall_voxels_fetch(c, pairs, coords, ms_out, false);
+}
+
+TA_API int ta_wall_voxels_get_by_pair(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_out) {
+    return wall_voxels_fetch(c, pairs, coords, ms_out, true);
 }
 
 TA_API int ta_volume_max_label(ta_ctx* c, uint32_t* max_label) {

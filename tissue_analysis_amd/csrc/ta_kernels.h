@@ -38,6 +38,12 @@ void launch_wall_emit(hipStream_t s, const void* vol, int itemsize, int64_t n0, 
                       const uint32_t* counts, const uint8_t* lane_counts, const uint64_t* offsets, uint32_t* out_pairs,
                       int32_t* out_coords, const int perm[3]);
 
+// kernels_wallsort.hip -- the records grouped by pair (stable radix sort by lo << 32 | hi, then a gather)
+uint64_t wall_sort_temp_bytes(uint64_t n);
+hipError_t launch_wall_group_by_pair(hipStream_t s, const uint32_t* pairs, const int32_t* coords, uint64_t n, uint64_t* keys0,
+                                     uint64_t* keys1, uint32_t* index0, uint32_t* index1, void* temp, uint64_t temp_bytes,
+                                     int key_bits_lo, uint32_t* pairs_out, int32_t* coords_out);
+
 // kernels_basic.hip (continued)
 void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3], int64_t a_begin,
                   int64_t a_count, const int32_t* seeds_dev, const int32_t grid[3],

@@ -237,8 +237,11 @@ class ResidentVolume(object):
         return x
 
     def wall_table(self):
+        if self.host.flags.c_contiguous:       # memory order IS np.where order: the device groups the records by pair
+            lo, hi, coords, ms = self.ctx.wall_voxels(by_pair=True)
+            return WallTable(lo, hi, coords, ms, grouped=True)
         lo, hi, coords, ms = self.ctx.wall_voxels()
-        if not self.host.flags.c_contiguous and coords.shape[0]:   # records come in memory order: np.where order wanted
+        if coords.shape[0]:                    # records come in memory order: np.where order wanted
             order = np.lexsort((coords[:, 2], coords[:, 1], coords[:, 0]))
             lo, hi, coords = lo[order], hi[order], coords[order]
         return WallTable(lo, hi, coords, ms)
@@ -307,11 +310,14 @@ class WallTable(object):
     """Wall voxels of every label pair of one image (SIA:759-880), from one GPU pass: records sorted by
     pair, each pair's voxels in np.where order of the image (lexicographic in the array axes)."""
 
-    def __init__(self, lo, hi, coords, ms=None):
+    def __init__(self, lo, hi, coords, ms=None, grouped=False):
         key = (lo.astype(np.uint64) << np.uint64(32)) | hi.astype(np.uint64)
-        order = np.argsort(key, kind="stable")
-        self.key = key[order]
-        self.coords = coords[order]
+        if grouped:                            # ta_wall_voxels_get_by_pair: already sorted by pair on the device
+            self.key, self.coords = key, coords
+        else:
+            order = np.argsort(key, kind="stable")
+            self.key = key[order]
+            self.coords = coords[order]
         self.ms = ms
         if self.key.size:
             cut = np.flatnonzero(self.key[1:] != self.key[:-1]) + 1
