@@ -123,18 +123,24 @@ void launch_max_label(hipStream_t s, const void* vol, int itemsize, uint64_t nvo
 // adjacency hash: collect (and self-clean), insert, clear
 // Each block owns a contiguous slot range: count its occupied slots, reserve output space with
 // ONE returning atomic per block (a single hot word sustains only ~88 atomics/us), then write.
+constexpr int COLLECT_PER_THREAD = 8;
 __global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64_t* out_keys,
-                                                            uint64_t* out_faces, uint32_t* cursor,
-                                                            uint32_t slots_per_block) {
+                                                            uint64_t* out_faces, uint32_t* cursor) {
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t block_base;
     const uint64_t cap = (uint64_t)pt.mask + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint64_t lo = (uint64_t)blockIdx.x * slots_per_block;
-    const uint64_t hi = lo + slots_per_block < cap ? lo + slots_per_block : cap;
-    // pass 1: occupied slots per thread (coalesced 8-byte key reads)
+    const uint64_t lo = (uint64_t)blockIdx.x * (256 * COLLECT_PER_THREAD);
+    // the thread's keys are read ONCE, all loads in flight together (coalesced 8-byte reads), and kept in registers
+    uint64_t k[COLLECT_PER_THREAD];
     uint32_t mine = 0;
-    for (uint64_t h = lo + tid; h < hi; h += 256) mine += pt.keys[h] != EMPTY_KEY;
+#pragma unroll
+    for (int i = 0; i < COLLECT_PER_THREAD; ++i) {
+        const uint64_t h = lo + (uint64_t)i * 256 + tid;
+        k[i] = h < cap ? pt.keys[h] : EMPTY_KEY;
+    }
+#pragma unroll
+    for (int i = 0; i < COLLECT_PER_THREAD; ++i) mine += k[i] != EMPTY_KEY;
     // wave inclusive scan, then block offsets
     uint32_t incl = mine;
 #pragma unroll
@@ -151,11 +157,12 @@ __global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64
     __syncthreads();
     uint32_t pos = block_base + incl - mine;
     for (int i = 0; i < w; ++i) pos += wave_tot[i];
-    // pass 2: emit and self-clean (keys come back from L2)
-    for (uint64_t h = lo + tid; h < hi; h += 256) {
-        const uint64_t k = pt.keys[h];
-        if (k == EMPTY_KEY) continue;
-        out_keys[pos] = k;
+    // emit and self-clean (order inside the list does not matter: the host getter sorts)
+#pragma unroll
+    for (int i = 0; i < COLLECT_PER_THREAD; ++i) {
+        if (k[i] == EMPTY_KEY) continue;
+        const uint64_t h = lo + (uint64_t)i * 256 + tid;
+        out_keys[pos] = k[i];
         out_faces[3ull * pos + 0] = pt.faces[3 * h + 0];
         out_faces[3ull * pos + 1] = pt.faces[3 * h + 1];
         out_faces[3ull * pos + 2] = pt.faces[3 * h + 2];
@@ -168,12 +175,10 @@ __global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64
 void launch_pairs_collect(hipStream_t s, const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces,
                           uint32_t* cursor) {
     const uint64_t cap = (uint64_t)pt.mask + 1;
-    uint64_t blocks = cap / 2048;
-    if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;
-    const uint32_t per_block = (uint32_t)((cap + blocks - 1) / blocks);
+    const uint64_t per_block = 256 * COLLECT_PER_THREAD;
+    const uint64_t blocks = (cap + per_block - 1) / per_block;
     hipLaunchKernelGGL(pairs_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pt, out_keys,
-                       out_faces, cursor, per_block);
+                       out_faces, cursor);
 }
 
 __global__ void __launch_bounds__(256) pairs_insert_kernel(PairTable pt, const uint64_t* keys,
