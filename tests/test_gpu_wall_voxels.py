@@ -118,3 +118,21 @@ def test_records_grouped_on_the_device_equal_the_host_sort():
             assert np.array_equal(table.key, want.key) and np.array_equal(table.coords, want.coords)
         finally:
             rv.close()
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 7, 1), (4, 6, 1), (5, 1, 9), (2, 2, 2), (3, 17, 5), (1, 1, 300), (2, 3, 257)])
+def test_degenerate_and_ragged_shapes(shape):
+    """Planes / rows / columns of extent 1, a strip of one column past 256, odd sizes: every pair's wall voxels against
+    the reference's dilations (the kernel clamps out-of-volume neighbours instead of testing for them)."""
+    rng = np.random.default_rng(sum(shape))
+    for dtype in (np.uint16, np.uint32):
+        vol = rng.integers(1, 5, size=shape).astype(dtype)
+        sia, ref = both(vol)
+        neigh = ref.neighbors()
+        labels = ref.labels()
+        for a in labels:
+            for b in labels:
+                if a < b:
+                    want = ref.wall_voxels_between_two_cells(a, b)
+                    got = sia.wall_voxels_between_two_cells(a, b)
+                    assert got.shape == want.shape and np.array_equal(got, want), (shape, dtype, a, b)
