@@ -124,10 +124,21 @@ void launch_max_label(hipStream_t s, const void* vol, int itemsize, uint64_t nvo
 // Each block owns a contiguous slot range: count its occupied slots, reserve output space with
 // ONE returning atomic per block (a single hot word sustains only ~88 atomics/us), then write.
 constexpr int COLLECT_PER_THREAD = 8;
+// `publish` (optional): host-mapped mirror of the flag words + cursor.  The block that finishes LAST copies them there, so
+// the step needs no device-to-host copy (a blit kernel + a queue barrier) after this kernel.
+__device__ __forceinline__ void publish_small(const uint32_t* small, uint32_t* publish, int nwords, int tid) {
+    if (tid < nwords) {
+        const uint32_t v = __hip_atomic_load(&small[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&publish[tid], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 __global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64_t* out_keys,
-                                                            uint64_t* out_faces, uint32_t* cursor) {
+                                                            uint64_t* out_faces, uint32_t* cursor, uint32_t* small,
+                                                            uint32_t* publish, int nwords) {
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t block_base;
+    __shared__ uint32_t is_last;
     const uint64_t cap = (uint64_t)pt.mask + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint64_t lo = (uint64_t)blockIdx.x * (256 * COLLECT_PER_THREAD);
@@ -170,15 +181,27 @@ __global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64
         pt.keys[h] = EMPTY_KEY;                              // leave the table clean for the next call
         pt.faces[3 * h + 0] = 0; pt.faces[3 * h + 1] = 0; pt.faces[3 * h + 2] = 0;
     }
+    if (publish) {
+        __syncthreads();                                     // (every block's cursor add precedes its own count below)
+        if (tid == 0) {
+            __threadfence();
+            is_last = atomicAdd(&small[FLAG_COLLECT_DONE], 1u) == gridDim.x - 1u;
+        }
+        __syncthreads();
+        if (is_last) {
+            if (tid == 0) small[FLAG_COLLECT_DONE] = 0u;
+            publish_small(small, publish, nwords, tid);
+        }
+    }
 }
 
 void launch_pairs_collect(hipStream_t s, const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces,
-                          uint32_t* cursor) {
+                          uint32_t* cursor, uint32_t* small, uint32_t* publish, int nwords) {
     const uint64_t cap = (uint64_t)pt.mask + 1;
     const uint64_t per_block = 256 * COLLECT_PER_THREAD;
     const uint64_t blocks = (cap + per_block - 1) / per_block;
     hipLaunchKernelGGL(pairs_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pt, out_keys,
-                       out_faces, cursor);
+                       out_faces, cursor, small, publish, nwords);
 }
 
 __global__ void __launch_bounds__(256) pairs_insert_kernel(PairTable pt, const uint64_t* keys,
@@ -340,8 +363,11 @@ void launch_pairs_clear(hipStream_t s, const PairTable& pt) {
 // global row.  Row = 128 bytes: sums u64[NSUM] | boxes i32[NBOX] | padding.
 __global__ void __launch_bounds__(256) hot_reduce_kernel(const uint64_t* __restrict__ rows, uint32_t nrows,
                                                          const void* vol, int itemsize, int64_t corner,
-                                                         uint64_t* sums, int32_t* boxes, uint32_t max_label) {
+                                                         uint64_t* sums, int32_t* boxes, uint32_t max_label,
+                                                         const uint32_t* small, uint32_t* publish, int nwords) {
     __shared__ uint64_t part[256];
+    // last kernel of a step without adjacency: the sweep's flags are final, block 0 mirrors them to the host
+    if (publish && blockIdx.x == 0) publish_small(small, publish, nwords, (int)threadIdx.x);
     const uint32_t hot = itemsize == 2 ? (uint32_t)((const uint16_t*)vol)[corner] : ((const uint32_t*)vol)[corner];
     if (hot > max_label) return;                           // the sweep has raised FLAG_RANGE already
     const int col = threadIdx.x & (HOTW - 1), lanegrp = threadIdx.x / HOTW;          // 16 row-lanes per block
@@ -367,12 +393,13 @@ __global__ void __launch_bounds__(256) hot_reduce_kernel(const uint64_t* __restr
     }
 }
 
-void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows) {
+void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows,
+                       uint32_t* publish, int nwords) {
     if (!hot_rows || nrows == 0) return;
     uint32_t blocks = (nrows + 15) / 16;
     if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL(hot_reduce_kernel, dim3(blocks), dim3(256), 0, s, hot_rows, nrows, a.vol, itemsize,
-                       (int64_t)a.first_owned * a.n1 * a.n2, a.sums, a.boxes, a.max_label);
+                       (int64_t)a.first_owned * a.n1 * a.n2, a.sums, a.boxes, a.max_label, a.flags, publish, nwords);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -84,7 +84,8 @@ struct ta_ctx {
     int pair_log2 = 0;                                  // current table log2 capacity
     int opt_pair_log2 = 0;
     bool table_clean = false;
-    uint32_t* h_small = nullptr;                        // pinned mirror of `small`
+    uint32_t* h_small = nullptr;                        // pinned, device-mapped mirror of `small`
+    uint32_t* h_small_dev = nullptr;                    // its device address: the last kernel of a step writes it
 
     // options / state
     int impl = 0;
@@ -179,13 +180,23 @@ int run_extract(ta_ctx* c) {
     if (c->impl == 1) ta::launch_naive(c->stream, a, c->itemsize, c->feature_mask);
     else              ta::launch_scan(c->stream, a, c->itemsize, c->feature_mask);
     TA_HIP(hipEventRecord(c->ev[2], c->stream));        // [1,2) = the sweep kernel alone (what the roofline is quoted on)
-    if (hot_rows) ta::launch_hot_reduce(c->stream, a, c->itemsize, hot_rows, (uint32_t)nwg);
-    if (adj)
+    // The LAST kernel of the step mirrors the flag words + pair count into host-mapped memory itself: no device-to-host
+    // copy (a blit kernel and a queue barrier) at the end of every step.
+    uint32_t* mirror = c->h_small_dev;
+    bool published = false;
+    if (hot_rows) {
+        ta::launch_hot_reduce(c->stream, a, c->itemsize, hot_rows, (uint32_t)nwg, adj ? nullptr : mirror, SMALL_WORDS);
+        published = !adj && mirror;
+    }
+    if (adj) {
         ta::launch_pairs_collect(c->stream, a.pairs, (uint64_t*)c->out_keys.p, (uint64_t*)c->out_faces.p,
-                                 cursor_dev(c));
+                                 cursor_dev(c), flags_dev(c), mirror, SMALL_WORDS);
+        published = mirror != nullptr;
+    }
     TA_HIP(hipEventRecord(c->ev[3], c->stream));
-    TA_HIP(hipMemcpyAsync(c->h_small, c->small.p, SMALL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost,
-                          c->stream));
+    if (!published)
+        TA_HIP(hipMemcpyAsync(c->h_small, c->small.p, SMALL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost,
+                              c->stream));
     TA_HIP(hipGetLastError());
     return TA_OK;
 }
@@ -263,7 +274,12 @@ TA_API int ta_ctx_create(int device_id, ta_ctx** out) {
     if (e == hipSuccess) c->own_stream = true;
     for (auto& ev : c->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     if (e == hipSuccess) rc = c->small.reserve(SMALL_WORDS * sizeof(uint32_t));
-    if (e == hipSuccess && rc == TA_OK) e = hipHostMalloc((void**)&c->h_small, SMALL_WORDS * sizeof(uint32_t), hipHostMallocDefault);
+    if (e == hipSuccess && rc == TA_OK) e = hipHostMalloc((void**)&c->h_small, SMALL_WORDS * sizeof(uint32_t), hipHostMallocMapped);
+    if (e == hipSuccess && rc == TA_OK) {
+        void* dp = nullptr;
+        if (hipHostGetDevicePointer(&dp, c->h_small, 0) == hipSuccess) c->h_small_dev = (uint32_t*)dp;
+        else (void)hipGetLastError();          // no mapping: the steps fall back to the device-to-host copy
+    }
     if (e != hipSuccess || rc != TA_OK) {
         if (e != hipSuccess) rc = fail(e == hipErrorOutOfMemory ? TA_ENOMEM : TA_EHIP, "ta_ctx_create: %s", hipGetErrorString(e));
         const std::string keep = g_err;
