@@ -62,6 +62,10 @@ extern "C" {
                                  with the sweep: the two cross-check each other on the GPU) */
 #define TA_OPT_TILE_PLANES 2  /* planes of memory axis 0 walked by one workgroup (tuning)          */
 #define TA_OPT_PAIR_SLOTS  3  /* log2 of the device adjacency hash capacity (0 = automatic)       */
+#define TA_OPT_TIMING      4  /* HIP events per extraction (an event record costs ~4 us of queue time):
+                               * 0 none, 1 = around the sweep kernel (default), 2 = also the step's begin / end */
+#define TA_OPT_TIMING_RING 5  /* sweep durations kept for ta_timing_series: the last N extractions, N in [1,4096]
+                               * (default 1); setting it drains the stream and starts a new series             */
 
 typedef struct ta_ctx ta_ctx;
 
@@ -119,9 +123,12 @@ TA_API int ta_get_labels(ta_ctx* ctx, uint64_t* count, int32_t* bbox, uint64_t* 
 TA_API int ta_adjacency_size(ta_ctx* ctx, int64_t* npairs);
 TA_API int ta_adjacency_get(ta_ctx* ctx, uint32_t* lo, uint32_t* hi, uint64_t* faces);
 
-/* Timing of the last ta_extract (HIP events on the context stream): the sweep kernel alone, what follows
- * it (fold of the per-workgroup hot-label rows + adjacency collection), the whole call from the accumulator
- * init on; bytes_read = nvox * itemsize (algorithmic bytes). */
+/* Timing of the last ta_extract (HIP events on the context stream): the sweep kernel alone; with TA_OPT_TIMING = 2
+ * also what follows it (fold of the per-workgroup hot-label rows + adjacency collection) and the whole call from
+ * the accumulator init on (0 otherwise); bytes_read = nvox * itemsize (algorithmic bytes).
+ * ta_timing_series: the sweep kernel's duration of each of the last extractions (oldest first, at most capacity and
+ * at most TA_OPT_TIMING_RING of them) -- drains the stream; how a host times every launch of a pipelined loop. */
+TA_API int ta_timing_series(ta_ctx* ctx, double* ms_sweep, int capacity, int* count);
 TA_API int ta_timing(ta_ctx* ctx, double* ms_sweep, double* ms_adjacency, double* ms_total,
               uint64_t* bytes_read);
 

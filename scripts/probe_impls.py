@@ -32,6 +32,7 @@ torch.cuda.synchronize()
 print("synth %.2fs dims=%s dtype=%s max_label=%d ellipsoid=%s" % (time.time() - t0, dims, dtype, max_label,
                                                                   not args.no_ellipsoid), flush=True)
 ctx.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, keep=vol)
+ctx.set_option(_capi.OPT_TIMING, 2)          # also the step's begin / end events (adj / total columns)
 ref = {}
 for feats in args.feat:
     for impl in args.impl:

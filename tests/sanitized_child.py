@@ -57,6 +57,7 @@ def walk_c_abi():
         "ta_adjacency_size": (None, ctypes.byref(i64)),
         "ta_adjacency_get": (None, buf, buf, buf),
         "ta_timing": (None, ctypes.byref(dbl), ctypes.byref(dbl), ctypes.byref(dbl), None),
+        "ta_timing_series": (None, ctypes.byref(dbl), 1, ctypes.byref(ctypes.c_int(0))),
         "ta_read_probe": (None, buf, 256, 1, ctypes.byref(dbl)),
         "ta_debug_counters": (None, buf),
         "ta_bind_accumulators": (None, buf, buf, 3),

@@ -18,7 +18,7 @@ F_VOLUME, F_BBOX, F_MOMENT1, F_MOMENT2, F_ADJACENCY = 1, 2, 4, 8, 16
 F_ALL = 31
 FEATURES = dict(VOLUME=F_VOLUME, BBOX=F_BBOX, MOMENT1=F_MOMENT1, MOMENT2=F_MOMENT2,
                 ADJACENCY=F_ADJACENCY)
-OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS = 1, 2, 3
+OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS, OPT_TIMING, OPT_TIMING_RING = 1, 2, 3, 4, 5
 STREAM_LEGACY_DEFAULT = 1          # TA_STREAM_LEGACY_DEFAULT of include/tissue_scan.h
 
 # every symbol include/tissue_scan.h declares
@@ -28,7 +28,7 @@ SYMBOLS = (
     "ta_volume_set_device", "ta_volume_max_label", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
     "ta_volume_first_layer", "ta_wall_voxels_count", "ta_wall_voxels_get", "ta_wall_voxels_get_by_pair",
     "ta_extract", "ta_get_labels",
-    "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_read_probe", "ta_debug_counters", "ta_bind_accumulators",
+    "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_timing_series", "ta_read_probe", "ta_debug_counters", "ta_bind_accumulators",
     "ta_accumulators_device", "ta_accumulators_reduced", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge",
     "ta_adjacency_pack", "ta_adjacency_pack_shared", "ta_adjacency_merge_blocks", "ta_synth_voronoi",
     "ta_device_malloc", "ta_device_free", "ta_memcpy_d2h", "ta_memcpy_h2d",
@@ -95,6 +95,7 @@ def load():
         "ta_adjacency_size": (ci, [vp, P(i64)]),
         "ta_adjacency_get": (ci, [vp, vp, vp, vp]),
         "ta_timing": (ci, [vp, P(ctypes.c_double), P(ctypes.c_double), P(ctypes.c_double), P(u64)]),
+        "ta_timing_series": (ci, [vp, P(ctypes.c_double), ci, P(ci)]),
         "ta_read_probe": (ci, [vp, vp, u64, ci, P(ctypes.c_double)]),
         "ta_debug_counters": (ci, [vp, P(u32)]),
         "ta_bind_accumulators": (ci, [vp, vp, vp, u32]),
@@ -319,6 +320,13 @@ class Context(object):
         _check(self._lib.ta_timing(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(t),
                                    ctypes.byref(nbytes)))
         return dict(ms_sweep=a.value, ms_adjacency=b.value, ms_total=t.value, bytes_read=nbytes.value)
+
+    def timing_series(self, capacity=4096):
+        """Sweep-kernel milliseconds of the last extractions (oldest first; OPT_TIMING_RING of them at most)."""
+        buf = (ctypes.c_double * int(capacity))()
+        n = ctypes.c_int(0)
+        _check(self._lib.ta_timing_series(self._h, buf, int(capacity), ctypes.byref(n)))
+        return [buf[i] for i in range(n.value)]
 
     def read_probe(self, dev_ptr, nbytes, repeats=5):
         """Milliseconds of the fastest of `repeats` read-only streaming passes over a device buffer."""

@@ -56,7 +56,10 @@ struct ta_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // [0] step begin, [3] step end (TA_OPT_TIMING = 2 only)
+    std::vector<hipEvent_t> ring;                       // 2 events per slot around the sweep kernel of the last `ring.size()/2` extractions
+    int timing = 1;                                     // TA_OPT_TIMING
+    uint64_t extract_seq = 0, ring_since = 0;           // extractions run; the one the ring's oldest valid slot belongs to
 
     // resident volume
     const void* vol = nullptr;       // device pointer (owned_vol.p or adopted)
@@ -170,16 +173,27 @@ int run_extract(ta_ctx* c) {
     }
 
     const bool adj = c->feature_mask & TA_F_ADJACENCY;
-    TA_HIP(hipEventRecord(c->ev[0], c->stream));
+    // A hipEventRecord costs ~4 us of queue time: by default only the sweep kernel is bracketed (TA_OPT_TIMING)
+    const size_t nslots = c->ring.size() / 2;
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    if (c->timing >= 1 && nslots) {
+        ev_a = c->ring[2 * (c->extract_seq % nslots)];
+        ev_b = c->ring[2 * (c->extract_seq % nslots) + 1];
+        if (c->extract_seq - c->ring_since >= nslots) c->ring_since = c->extract_seq - nslots + 1;
+    } else {
+        c->ring_since = c->extract_seq + 1;
+    }
+    ++c->extract_seq;
+    if (c->timing >= 2) TA_HIP(hipEventRecord(c->ev[0], c->stream));
     if (adj && !c->table_clean) {
         ta::launch_pairs_clear(c->stream, a.pairs);
         c->table_clean = true;
     }
     ta::launch_init_accumulators(c->stream, c->sums, c->boxes, nlabels, flags_dev(c), cursor_dev(c), hot_rows);
-    TA_HIP(hipEventRecord(c->ev[1], c->stream));
+    if (ev_a) TA_HIP(hipEventRecord(ev_a, c->stream));
     if (c->impl == 1) ta::launch_naive(c->stream, a, c->itemsize, c->feature_mask);
     else              ta::launch_scan(c->stream, a, c->itemsize, c->feature_mask);
-    TA_HIP(hipEventRecord(c->ev[2], c->stream));        // [1,2) = the sweep kernel alone (what the roofline is quoted on)
+    if (ev_b) TA_HIP(hipEventRecord(ev_b, c->stream));           // the sweep kernel alone (what the roofline is quoted on)
     // The LAST kernel of the step mirrors the flag words + pair count into host-mapped memory itself: no device-to-host
     // copy (a blit kernel and a queue barrier) at the end of every step.
     uint32_t* mirror = c->h_small_dev;
@@ -193,7 +207,7 @@ int run_extract(ta_ctx* c) {
                                  cursor_dev(c), flags_dev(c), mirror, SMALL_WORDS);
         published = mirror != nullptr;
     }
-    TA_HIP(hipEventRecord(c->ev[3], c->stream));
+    if (c->timing >= 2) TA_HIP(hipEventRecord(c->ev[3], c->stream));
     if (!published)
         TA_HIP(hipMemcpyAsync(c->h_small, c->small.p, SMALL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost,
                               c->stream));
@@ -273,6 +287,8 @@ TA_API int ta_ctx_create(int device_id, ta_ctx** out) {
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e == hipSuccess) c->own_stream = true;
     for (auto& ev : c->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
+    try { c->ring.assign(2, nullptr); } catch (...) { rc = fail(TA_ENOMEM, "out of host memory"); }
+    for (auto& ev : c->ring) if (e == hipSuccess && rc == TA_OK) e = hipEventCreate(&ev);
     if (e == hipSuccess) rc = c->small.reserve(SMALL_WORDS * sizeof(uint32_t));
     if (e == hipSuccess && rc == TA_OK) e = hipHostMalloc((void**)&c->h_small, SMALL_WORDS * sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess && rc == TA_OK) {
@@ -303,6 +319,7 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     c->wall_counts.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->ring) if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TA_OK;
@@ -340,6 +357,24 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
         case TA_OPT_PAIR_SLOTS:
             if (value != 0 && (value < 4 || value > 30)) return fail(TA_EINVAL, "TA_OPT_PAIR_SLOTS must be 0 or in [4,30]");
             c->opt_pair_log2 = (int)value; return TA_OK;
+        case TA_OPT_TIMING:
+            if (value < 0 || value > 2) return fail(TA_EINVAL, "TA_OPT_TIMING must be 0, 1 or 2");
+            c->timing = (int)value; return TA_OK;
+        case TA_OPT_TIMING_RING: {
+            if (value < 1 || value > 4096) return fail(TA_EINVAL, "TA_OPT_TIMING_RING must be in [1,4096]");
+            int rc = use_device(c);
+            if (rc != TA_OK) return rc;
+            if (c->stream) TA_HIP(hipStreamSynchronize(c->stream));
+            const size_t want = 2 * (size_t)value;
+            while (c->ring.size() > want) { (void)hipEventDestroy(c->ring.back()); c->ring.pop_back(); }
+            while (c->ring.size() < want) {
+                hipEvent_t ev = nullptr;
+                TA_HIP(hipEventCreate(&ev));
+                try { c->ring.push_back(ev); } catch (...) { (void)hipEventDestroy(ev); return fail(TA_ENOMEM, "out of host memory"); }
+            }
+            c->ring_since = c->extract_seq;          // the kept durations start with the next extraction
+            return TA_OK;
+        }
         default:
             return fail(TA_EINVAL, "unknown option key %d", key);
     }
@@ -349,6 +384,8 @@ TA_API int ta_ctx_get_option(ta_ctx* c, int key, int64_t* value) {
     if (!c || !value) return fail(TA_EINVAL, "NULL argument");
     switch (key) {
         case TA_OPT_IMPL: *value = c->impl; return TA_OK;
+        case TA_OPT_TIMING: *value = c->timing; return TA_OK;
+        case TA_OPT_TIMING_RING: *value = (int64_t)(c->ring.size() / 2); return TA_OK;
         case TA_OPT_TILE_PLANES: *value = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY); return TA_OK;
         case TA_OPT_PAIR_SLOTS: *value = c->pkeys.p ? c->pair_log2 : c->opt_pair_log2; return TA_OK;
         default: return fail(TA_EINVAL, "unknown option key %d", key);
@@ -767,16 +804,42 @@ TA_API int ta_timing(ta_ctx* c, double* ms_sweep, double* ms_adjacency, double* 
     if (!c->extracted) return fail(TA_EINVAL, "no extraction has been run on this context");
     int rc = use_device(c);
     if (rc != TA_OK) return rc;
-    TA_HIP(hipEventSynchronize(c->ev[3]));
+    const size_t nslots = c->ring.size() / 2;
     float a = 0, b = 0, t = 0;
-    TA_HIP(hipEventElapsedTime(&a, c->ev[1], c->ev[2]));
-    TA_HIP(hipEventElapsedTime(&b, c->ev[2], c->ev[3]));
-    TA_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
+    if (c->extract_seq > c->ring_since && nslots) {          // the last extraction recorded its sweep events
+        hipEvent_t ev_a = c->ring[2 * ((c->extract_seq - 1) % nslots)], ev_b = c->ring[2 * ((c->extract_seq - 1) % nslots) + 1];
+        TA_HIP(hipEventSynchronize(ev_b));
+        TA_HIP(hipEventElapsedTime(&a, ev_a, ev_b));
+        if (c->timing >= 2) {
+            TA_HIP(hipEventSynchronize(c->ev[3]));
+            TA_HIP(hipEventElapsedTime(&b, ev_b, c->ev[3]));
+            TA_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
+        }
+    } else if (ms_sweep || ms_adjacency || ms_total) {
+        return fail(TA_EINVAL, "the last extraction recorded no events (TA_OPT_TIMING is 0)");
+    }
     if (ms_sweep) *ms_sweep = a;
     if (ms_adjacency) *ms_adjacency = b;
     if (ms_total) *ms_total = t;
     if (bytes_read)
         *bytes_read = (uint64_t)(c->mdims[0] - c->first_owned) * c->mdims[1] * c->mdims[2] * c->itemsize;
+    return TA_OK;
+}
+
+TA_API int ta_timing_series(ta_ctx* c, double* ms_sweep, int capacity, int* count) {
+    if (!c || !count || (capacity > 0 && !ms_sweep) || capacity < 0) return fail(TA_EINVAL, "NULL ctx / output or negative capacity");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const size_t nslots = c->ring.size() / 2;
+    uint64_t first = c->ring_since, last = c->extract_seq;          // extractions [first, last) have valid events
+    if (last - first > (uint64_t)capacity) first = last - (uint64_t)capacity;
+    *count = 0;
+    if (c->stream) TA_HIP(hipStreamSynchronize(c->stream));
+    for (uint64_t q = first; q < last && nslots; ++q) {
+        float ms = 0;
+        TA_HIP(hipEventElapsedTime(&ms, c->ring[2 * (q % nslots)], c->ring[2 * (q % nslots) + 1]));
+        ms_sweep[(*count)++] = ms;
+    }
     return TA_OK;
 }
 
