@@ -103,22 +103,27 @@ __device__ __forceinline__ const SweepArgs* kernarg_args(const SweepArgs& by_val
 #endif
 }
 
+__device__ __forceinline__ uint32_t scan_label_hash(uint32_t label) {
+    return (__umul24(label, 0x9E3779u) >> (24 - LSLOTS_LOG2)) & (LSLOTS - 1);
+}
+
+// `h`, `k` = the label's home slot and the key read from it: the caller issues that read early, together with the
+// other table's, so the two LDS round trips overlap.  (A key read as empty may be taken by now: the CAS tells.)
 template <bool MOM2, typename LDS, typename SUMS>
 __device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S,
                                                uint32_t label, const SUMS& L, uint32_t mna, uint32_t mxa, uint32_t mnb,
-                                               uint32_t mxb, uint32_t mnc, uint32_t mxc) {
+                                               uint32_t mxb, uint32_t mnc, uint32_t mxc, uint32_t h, uint32_t k) {
     constexpr int NW = MOM2 ? 6 : 2;
-    uint32_t h = (__umul24(label, 0x9E3779u) >> (24 - LSLOTS_LOG2)) & (LSLOTS - 1);
     int slot = -1;
 #pragma nounroll
     for (int probe = 0; probe < LPROBE; ++probe) {
-        uint32_t k = S.lkeys[h];
         if (k == INVALID_LABEL) {
             k = atomicCAS(&S.lkeys[h], INVALID_LABEL, label);
             if (k == INVALID_LABEL) k = label;
         }
         if (k == label) { slot = (int)h; break; }
         h = (h + 1) & (LSLOTS - 1);
+        k = S.lkeys[h];
     }
     if (slot >= 0) {
         unsigned long long* row = (unsigned long long*)&S.lsum[slot * NW];
@@ -151,22 +156,26 @@ __device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S,
     }
 }
 
+__device__ __forceinline__ uint32_t scan_pair_hash(uint32_t lo, uint32_t hi) {
+    const uint32_t h = __umul24(lo, 0x9E3779u) + __umul24(hi, 0x85EBCBu);     // two full-rate 24-bit multiplies, modulo 2^24
+    return (h >> (24 - PSLOTS_LOG2)) & (PSLOTS - 1);
+}
+
+// (h, k: the pair's home slot and the key read from it by the caller, see scan_label_add)
 template <typename LDS>
-__device__ __forceinline__ void scan_pair_add(const SweepArgs* kp, LDS& S, uint32_t a, uint32_t b, uint32_t axis) {
-    const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
+__device__ __forceinline__ void scan_pair_add(const SweepArgs* kp, LDS& S, uint32_t lo, uint32_t hi, uint32_t axis, uint32_t h,
+                                              uint64_t k) {
     const uint64_t key = ((uint64_t)lo << 32) | hi;
-    uint32_t h = __umul24(lo, 0x9E3779u) + __umul24(hi, 0x85EBCBu);     // two full-rate 24-bit multiplies, modulo 2^24
-    h = (h >> (24 - PSLOTS_LOG2)) & (PSLOTS - 1);
     int slot = -1;
 #pragma nounroll
     for (int probe = 0; probe < PPROBE; ++probe) {
-        uint64_t k = S.pkeys[h];
         if (k == EMPTY_KEY) {
             k = atomicCAS((unsigned long long*)&S.pkeys[h], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
             if (k == EMPTY_KEY) k = key;
         }
         if (k == key) { slot = (int)h; break; }
         h = (h + 1) & (PSLOTS - 1);
+        k = S.pkeys[h];
     }
     if (slot >= 0) atomicAdd(&S.pcnt[slot * 3 + axis], 1u);
     else {
@@ -178,7 +187,8 @@ __device__ __forceinline__ void scan_pair_add(const SweepArgs* kp, LDS& S, uint3
 // one run [s, k) of a row (tile-local a, b): ten sums, every term < 2^32, every factor < 2^24
 template <bool MOM2, typename LDS>
 __device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S,
-                                                 const bool EDGE, uint32_t label, uint32_t s, uint32_t code) {
+                                                 const bool EDGE, uint32_t label, uint32_t s, uint32_t code, uint32_t lh,
+                                                 uint32_t lk) {
     const uint32_t c0 = s, k = code & 1023u, bl = (code >> 10) & 15u, al = (code >> 14) & 63u;
     const uint32_t n = k - c0;
     if (label >= LABEL_LIMIT) {
@@ -200,7 +210,7 @@ __device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S,
     } else {
         L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
     }
-    scan_label_add<MOM2, LDS, RunSums>(kp, S, label, L, al, al, bl, bl, c0, k - 1u);
+    scan_label_add<MOM2, LDS, RunSums>(kp, S, label, L, al, al, bl, bl, c0, k - 1u, lh, lk);
 }
 
 // Drain both buffers of a wave completely, 64 records per pass, every lane busy but in the last pass.
@@ -211,15 +221,20 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (TA_ABLATE >= 1) { fcount = 0u; rcount = 0u; return; }
     if (ADJ) {
-        for (uint32_t i = 0; i < fcount; i += 64u) {
-            const uint32_t idx = i + (uint32_t)lane;
-            const uint2 rec = W.frec[idx < (uint32_t)FCAP ? idx : 0u];
-            if (idx < fcount) {
-                const uint32_t v = rec.x, pv = rec.y & 0x3fffffffu, axis = rec.y >> 30;
-                // records that touch the outside-the-volume filler are dropped; a label the record words cannot
-                // carry (>= LABEL_LIMIT) raises FLAG_RANGE through the run record of its own voxel
-                if (v < LABEL_LIMIT && pv < LABEL_LIMIT) scan_pair_add(kp, S, pv, v, axis);
-            }
+        // two passes of 64 faces per iteration: the home-slot reads of both are in flight together
+        for (uint32_t i = 0; i < fcount; i += 128u) {
+            const uint32_t idx0 = i + (uint32_t)lane, idx1 = idx0 + 64u;
+            const uint2 rec0 = W.frec[idx0 < (uint32_t)FCAP ? idx0 : 0u], rec1 = W.frec[idx1 < (uint32_t)FCAP ? idx1 : 0u];
+            const uint32_t v0 = rec0.x, pv0 = rec0.y & 0x3fffffffu, v1 = rec1.x, pv1 = rec1.y & 0x3fffffffu;
+            // records that touch the outside-the-volume filler are dropped; a label the record words cannot
+            // carry (>= LABEL_LIMIT) raises FLAG_RANGE through the run record of its own voxel
+            const bool live0 = idx0 < fcount && v0 < LABEL_LIMIT && pv0 < LABEL_LIMIT;
+            const bool live1 = idx1 < fcount && v1 < LABEL_LIMIT && pv1 < LABEL_LIMIT;
+            const uint32_t lo0 = v0 < pv0 ? v0 : pv0, hi0 = v0 < pv0 ? pv0 : v0, lo1 = v1 < pv1 ? v1 : pv1, hi1 = v1 < pv1 ? pv1 : v1;
+            const uint32_t h0 = scan_pair_hash(lo0, hi0), h1 = scan_pair_hash(lo1, hi1);
+            const uint64_t k0 = S.pkeys[h0], k1 = S.pkeys[h1];
+            if (live0) scan_pair_add(kp, S, lo0, hi0, rec0.y >> 30, h0, k0);
+            if (live1) scan_pair_add(kp, S, lo1, hi1, rec1.y >> 30, h1, k1);
         }
         fcount = 0u;
     }
@@ -228,10 +243,15 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
         const uint32_t slot = idx < (uint32_t)RCAP ? idx : 0u;
         const uint32_t prev = W.cqc[slot], code = W.cqc[slot + 1u], label = W.cql[slot + 1u];
         const uint32_t v = ADJ ? W.cqv[slot + 1u] : 0u;
+        // the home slots of both tables are read before either is worked on
+        const uint32_t lo = label < v ? label : v, hi = label < v ? v : label;
+        const uint32_t ph = ADJ ? scan_pair_hash(lo, hi) : 0u, lh = scan_label_hash(label);
+        const uint64_t pk = ADJ ? S.pkeys[ph] : 0ull;
+        const uint32_t lk = S.lkeys[lh];
         if (idx < rcount) {
-            if (ADJ && v < LABEL_LIMIT && label < LABEL_LIMIT) scan_pair_add(kp, S, label, v, 2u);
+            if (ADJ && v < LABEL_LIMIT && label < LABEL_LIMIT) scan_pair_add(kp, S, lo, hi, 2u, ph, pk);
             const uint32_t s = ((prev ^ code) & ROWID_MASK) == 0u ? (prev & 1023u) : 0u;
-            consume_scan_run<MOM2, LDS>(kp, S, EDGE, label, s, code);
+            consume_scan_run<MOM2, LDS>(kp, S, EDGE, label, s, code, lh, lk);
         }
     }
     if (rcount) {
@@ -658,8 +678,9 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         }
         const uint32_t mxa = (uint32_t)(R ? P : P - 1u);
         const uint32_t mxb = (uint32_t)(b0 + (P ? RB : R) - 1u);
+        const uint32_t fh = scan_label_hash(first_label);
         scan_label_add<MOM2, LDS, LocalSums>(kp, S, first_label, L, 0u, mxa, (uint32_t)b0, mxb, 0u,
-                                             (uint32_t)(nc - 1));
+                                             (uint32_t)(nc - 1), fh, S.lkeys[fh]);
     }
 }
 
