@@ -24,6 +24,8 @@ for a in 1 2 3; do
   fi
 done
 echo "full" >> gpurun_out/${TAG}_ablations.txt
-python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f 0x17 0x0f 0x07 --iters 7 2>&1 | grep "impl=0" | cut -c1-110 >> gpurun_out/${TAG}_ablations.txt
+python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f 0x17 0x0f 0x07 --iters 7 --no-check 2>&1 | grep "impl=0" | cut -c1-110 >> gpurun_out/${TAG}_ablations.txt
 python3 scripts/probe_impls.py C5 --impl 0 --feat 0x1f --iters 4 --no-check 2>&1 | grep "impl=0" | cut -c1-110 >> gpurun_out/${TAG}_ablations.txt
 python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f 0x0f --iters 5 --no-check --no-ellipsoid 2>&1 | grep "impl=0" | sed 's/^/tissue-filled /' | cut -c1-124 >> gpurun_out/${TAG}_ablations.txt
+python3 scripts/probe_impls.py C2 --impl 0 --feat 0x07 --iters 15 --no-check 2>&1 | grep "impl=0" | cut -c1-110 >> gpurun_out/${TAG}_ablations.txt
+python3 scripts/probe_walls.py C2 2>&1 | tail -2 >> gpurun_out/${TAG}_ablations.txt

@@ -124,8 +124,8 @@ void launch_max_label(hipStream_t s, const void* vol, int itemsize, uint64_t nvo
 // Each block owns a contiguous slot range: count its occupied slots, reserve output space with
 // ONE returning atomic per block (a single hot word sustains only ~88 atomics/us), then write.
 constexpr int COLLECT_PER_THREAD = 8;
-// `publish` (optional): host-mapped mirror of the flag words + cursor.  The block that finishes LAST copies them there, so
-// the step needs no device-to-host copy (a blit kernel + a queue barrier) after this kernel.
+// `publish`: host-mapped mirror of the flag words (+ cursor): written by a kernel whose predecessors have fixed them, so the
+// step needs no device-to-host copy (a blit kernel + a queue barrier) afterwards.
 __device__ __forceinline__ void publish_small(const uint32_t* small, uint32_t* publish, int nwords, int tid) {
     if (tid < nwords) {
         const uint32_t v = __hip_atomic_load(&small[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -134,11 +134,9 @@ __device__ __forceinline__ void publish_small(const uint32_t* small, uint32_t* p
 }
 
 __global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64_t* out_keys,
-                                                            uint64_t* out_faces, uint32_t* cursor, uint32_t* small,
-                                                            uint32_t* publish, int nwords) {
+                                                            uint64_t* out_faces, uint32_t* cursor) {
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t block_base;
-    __shared__ uint32_t is_last;
     const uint64_t cap = (uint64_t)pt.mask + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const uint64_t lo = (uint64_t)blockIdx.x * (256 * COLLECT_PER_THREAD);
@@ -181,27 +179,15 @@ __global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64
         pt.keys[h] = EMPTY_KEY;                              // leave the table clean for the next call
         pt.faces[3 * h + 0] = 0; pt.faces[3 * h + 1] = 0; pt.faces[3 * h + 2] = 0;
     }
-    if (publish) {
-        __syncthreads();                                     // (every block's cursor add precedes its own count below)
-        if (tid == 0) {
-            __threadfence();
-            is_last = atomicAdd(&small[FLAG_COLLECT_DONE], 1u) == gridDim.x - 1u;
-        }
-        __syncthreads();
-        if (is_last) {
-            if (tid == 0) small[FLAG_COLLECT_DONE] = 0u;
-            publish_small(small, publish, nwords, tid);
-        }
-    }
 }
 
 void launch_pairs_collect(hipStream_t s, const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces,
-                          uint32_t* cursor, uint32_t* small, uint32_t* publish, int nwords) {
+                          uint32_t* cursor) {
     const uint64_t cap = (uint64_t)pt.mask + 1;
     const uint64_t per_block = 256 * COLLECT_PER_THREAD;
     const uint64_t blocks = (cap + per_block - 1) / per_block;
     hipLaunchKernelGGL(pairs_collect_kernel, dim3((unsigned)blocks), dim3(256), 0, s, pt, out_keys,
-                       out_faces, cursor, small, publish, nwords);
+                       out_faces, cursor);
 }
 
 __global__ void __launch_bounds__(256) pairs_insert_kernel(PairTable pt, const uint64_t* keys,
@@ -397,7 +383,7 @@ void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const ui
                        uint32_t* publish, int nwords) {
     if (!hot_rows || nrows == 0) return;
     uint32_t blocks = (nrows + 15) / 16;
-    if (blocks > 64) blocks = 64;
+    if (blocks > 128) blocks = 128;
     hipLaunchKernelGGL(hot_reduce_kernel, dim3(blocks), dim3(256), 0, s, hot_rows, nrows, a.vol, itemsize,
                        (int64_t)a.first_owned * a.n1 * a.n2, a.sums, a.boxes, a.max_label, a.flags, publish, nwords);
 }

@@ -194,19 +194,18 @@ int run_extract(ta_ctx* c) {
     if (c->impl == 1) ta::launch_naive(c->stream, a, c->itemsize, c->feature_mask);
     else              ta::launch_scan(c->stream, a, c->itemsize, c->feature_mask);
     if (ev_b) TA_HIP(hipEventRecord(ev_b, c->stream));           // the sweep kernel alone (what the roofline is quoted on)
-    // The LAST kernel of the step mirrors the flag words + pair count into host-mapped memory itself: no device-to-host
-    // copy (a blit kernel and a queue barrier) at the end of every step.
+    // Without adjacency the LAST kernel of the step (the hot-row fold) mirrors the flag words into host-mapped memory
+    // itself: no device-to-host copy (a blit kernel and a queue barrier) at the end of the step.  With adjacency the pair
+    // count is final only when the collect kernel has ended; letting its last block publish it was measured and costs
+    // more (every block then waits for its own stores before it can count itself done: 29 -> 44 us) than the copy.
     uint32_t* mirror = c->h_small_dev;
     bool published = false;
     if (hot_rows) {
         ta::launch_hot_reduce(c->stream, a, c->itemsize, hot_rows, (uint32_t)nwg, adj ? nullptr : mirror, SMALL_WORDS);
         published = !adj && mirror;
     }
-    if (adj) {
-        ta::launch_pairs_collect(c->stream, a.pairs, (uint64_t*)c->out_keys.p, (uint64_t*)c->out_faces.p,
-                                 cursor_dev(c), flags_dev(c), mirror, SMALL_WORDS);
-        published = mirror != nullptr;
-    }
+    if (adj)
+        ta::launch_pairs_collect(c->stream, a.pairs, (uint64_t*)c->out_keys.p, (uint64_t*)c->out_faces.p, cursor_dev(c));
     if (c->timing >= 2) TA_HIP(hipEventRecord(c->ev[3], c->stream));
     if (!published)
         TA_HIP(hipMemcpyAsync(c->h_small, c->small.p, SMALL_WORDS * sizeof(uint32_t), hipMemcpyDeviceToHost,

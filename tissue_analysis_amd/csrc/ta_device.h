@@ -15,9 +15,7 @@ constexpr int NBOX = 6;                             // min0,min1,min2,-max0,-max
 
 // flag words written by kernels, read back by the host after the stream drains
 enum { FLAG_RANGE = 0, FLAG_PAIR_OVERFLOW = 1, FLAG_LDS_LABEL_SPILL = 2, FLAG_LDS_PAIR_SPILL = 3,
-       FLAG_EXCHANGE_OVERFLOW = 4,
-       FLAG_COLLECT_DONE = 15,     // not a flag: blocks of pairs_collect_kernel that have finished (the last one publishes)
-       NFLAGS = 16 };
+       FLAG_EXCHANGE_OVERFLOW = 4, NFLAGS = 16 };
 
 // Exchange block of one rank (multi-GPU adjacency merge), u64 words:
 //   [0] pair count n (may exceed the capacity: receivers flag the overflow)   [1] status bits
