@@ -17,8 +17,8 @@
 // the 3 x 3 x 3 block is one label).
 // Two passes over the same decomposition: COUNT writes one record count per (row, strip) and one byte per lane of it;
 // an exclusive scan ON THE DEVICE turns the former into offsets; EMIT starts each lane at the strip's offset plus the
-// lanes before it, so the records come out in memory order with no atomics and are stored the moment they are found,
-// already as (lo, hi) / coordinates in array-axis order.  The host reads back ONE number (the total)
+// lanes before it, so the records come out in memory order with no atomics and without a second walk over the columns
+// (a column's labels are stored as soon as its rounds are done), already as (lo, hi) / coordinates in array-axis order.  The host reads back ONE number (the total)
 // between the passes, to size the output.
 #include "ta_kernels.h"
 #include "ta_sweep_common.h"
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(256) wall_rows_kernel(WallArgs A) {
             Rc[f] = lane_shl1(side[f]->v[0], side[f]->hr);
         }
         // EMIT: where this lane's records go -- the row strip's offset plus the lanes before it (their totals were
-        // written by the count pass), so every label is stored the moment a round finds it
+        // written by the count pass), so a column's labels are stored as soon as its rounds are done
         uint32_t pos = 0;                       // relative to the strip's first record: 32-bit offsets from a scalar base
         uint2* out_pairs = nullptr;
         int32_t* out_coords = nullptr;
