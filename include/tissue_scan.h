@@ -115,7 +115,8 @@ TA_API int ta_extract(ta_ctx* ctx, uint32_t feature_mask, uint32_t max_label);
  *   count [L+1]     voxels per label
  *   bbox  [L+1][6]  min0,min1,min2,max0+1,max1+1,max2+1 ; -1 when the label is absent
  *   sum1  [L+1][3]  sum of coordinates
- *   sum2  [L+1][6]  sum of coordinate products, order 00,01,02,11,12,22 */
+ *   sum2  [L+1][6]  sum of coordinate products, order 00,01,02,11,12,22; zero when the extraction did not ask for
+ *                   TA_F_MOMENT2 (the device columns behind ta_accumulators_device are then undefined) */
 TA_API int ta_get_labels(ta_ctx* ctx, uint64_t* count, int32_t* bbox, uint64_t* sum1, uint64_t* sum2);
 
 /* Face-neighbour adjacency (size-then-fill): unique pairs lo<hi sorted by (lo,hi);

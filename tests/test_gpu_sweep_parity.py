@@ -113,3 +113,25 @@ def test_labels_the_records_cannot_carry_are_reported(gpu_ctx):
     with pytest.raises(_capi.TissueScanError) as e:
         run(gpu_ctx, vol, 0, max_label=1000)
     assert e.value.code == _capi.TA_ERANGE
+
+
+def test_table_spills_keep_every_mask_exact(gpu_ctx):
+    """Thousands of tiny cells per tile overflow the workgroup's label table (128 slots) and pair table (512): the
+    contributions that spill to the global rows must give the same results -- and must leave the second-moment columns
+    untouched (zero) when TA_F_MOMENT2 was not asked for, as the flush does."""
+    vol = random_blocks((48, 32, 512), 6000, 17, np.uint32)
+    want = onepass_c.extract(vol)
+    for features in (_capi.F_ALL, 0x17, 0x0f, 0x07):
+        x = extract_volume(vol, features, context=gpu_ctx, impl=0)
+        got = x.as_arrays()
+        for k in ("count", "bbox", "sum1"):
+            assert np.array_equal(got[k], want[k]), (hex(features), k)
+        if features & _capi.F_MOMENT2:
+            assert np.array_equal(got["sum2"], want["sum2"]), hex(features)
+        else:
+            assert not got["sum2"].any(), hex(features)
+        if features & _capi.F_ADJACENCY:
+            for k in ("pair_lo", "pair_hi", "pair_faces"):
+                assert np.array_equal(got[k], want[k]), (hex(features), k)
+    spills = gpu_ctx.debug_counters()
+    assert spills["label_spills"] > 0, spills          # (the case does what it is meant to)

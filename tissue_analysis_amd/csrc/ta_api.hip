@@ -741,11 +741,14 @@ TA_API int ta_get_labels(ta_ctx* c, uint64_t* count, int32_t* bbox, uint64_t* su
     // second-moment slot of an (array axis, array axis) pair
     auto pair_slot = [](int x, int y) { if (x > y) std::swap(x, y); return x == 0 ? y : (x == 1 ? 2 + y : 5); };
     static const int mem_pair[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
+    const bool mom2 = c->feature_mask & TA_F_MOMENT2;
     for (uint64_t l = 0; l < n; ++l) {
         if (count) count[l] = hs[l * ta::NSUM];
         if (sum1) for (int k = 0; k < 3; ++k) sum1[l * 3 + c->perm[k]] = hs[l * ta::NSUM + 1 + k];
+        // (without TA_F_MOMENT2 the device columns are not defined -- the rare table-spill path writes cross terms there --
+        //  and the getter answers zero)
         if (sum2) for (int q = 0; q < 6; ++q)
-            sum2[l * 6 + pair_slot(c->perm[mem_pair[q][0]], c->perm[mem_pair[q][1]])] = hs[l * ta::NSUM + 4 + q];
+            sum2[l * 6 + pair_slot(c->perm[mem_pair[q][0]], c->perm[mem_pair[q][1]])] = mom2 ? hs[l * ta::NSUM + 4 + q] : 0ull;
         if (bbox) {
             const bool present = hb[l * 6] != INT32_MAX;
             for (int k = 0; k < 3; ++k) {
