@@ -135,3 +135,27 @@ def test_table_spills_keep_every_mask_exact(gpu_ctx):
                 assert np.array_equal(got[k], want[k]), (hex(features), k)
     spills = gpu_ctx.debug_counters()
     assert spills["label_spills"] > 0, spills          # (the case does what it is meant to)
+
+
+def test_repeated_sweeps_of_a_spilling_volume_adapt_the_tile_height(gpu_ctx):
+    """The automatic tile height is halved (for the following sweeps of the same resident volume) when the workgroup
+    tables overflow: same results, fewer spills, less time."""
+    vol = random_blocks((96, 64, 512), 40000, 18, np.uint32, block=(5, 4, 9))
+    want = onepass_c.extract(vol)
+    gpu_ctx.set_option(_capi.OPT_TILE_PLANES, 0)
+    gpu_ctx.set_option(_capi.OPT_IMPL, 0)
+    gpu_ctx.set_volume(vol)
+    L = int(vol.max())
+    spills, ms = [], []
+    for _ in range(5):
+        gpu_ctx.extract(_capi.F_ALL, L)
+        count, bbox, sum1, sum2 = gpu_ctx.labels()
+        lo, hi, faces = gpu_ctx.adjacency()
+        assert np.array_equal(count, want["count"]) and np.array_equal(bbox, want["bbox"])
+        assert np.array_equal(sum1, want["sum1"]) and np.array_equal(sum2, want["sum2"])
+        assert np.array_equal(lo, want["pair_lo"]) and np.array_equal(hi, want["pair_hi"]) and np.array_equal(faces, want["pair_faces"])
+        d = gpu_ctx.debug_counters()
+        spills.append(d["label_spills"] + d["pair_spills"])
+        ms.append(gpu_ctx.timing()["ms_sweep"])
+    assert spills[0] > 0 and spills[-1] < spills[0] // 4, spills
+    assert ms[-1] < ms[0], ms

@@ -93,6 +93,8 @@ struct ta_ctx {
     // options / state
     int impl = 0;
     int tile_planes = 0;
+    int auto_tile_shift = 0;                            // automatic tile height halved this many times (table spills seen)
+    uint64_t last_grid = 0;                             // workgroups of the last sweep
     uint32_t feature_mask = 0;
     bool extracted = false, checked = false;
     bool exchanged = false;                             // adjacency rebuilt by ta_adjacency_merge_blocks
@@ -155,6 +157,9 @@ int run_extract(ta_ctx* c) {
     if (c->tile_planes <= 0) {
         // automatic: small volumes get shorter tiles until the launch has >= 2048 workgroups (8 per CU)
         while (a.tile_planes > 8 && ta::sweep_grid_size(a, c->itemsize) < 2048) a.tile_planes /= 2;
+        // volumes whose cells are so small that a tile holds more labels than the workgroup tables (the contributions
+        // then spill to global atomics, ~100x dearer) get shorter tiles still: see finish_extract
+        for (int k = 0; k < c->auto_tile_shift && a.tile_planes > 1; ++k) a.tile_planes /= 2;
     }
     if (a.tile_planes > ta::sweep_max_tile_planes()) a.tile_planes = ta::sweep_max_tile_planes();   // packed LDS moment words
     a.vec_ok = (((uintptr_t)c->vol & 15) == 0) && ((a.n2 * c->itemsize) % 16 == 0);
@@ -173,6 +178,7 @@ int run_extract(ta_ctx* c) {
     }
 
     const bool adj = c->feature_mask & TA_F_ADJACENCY;
+    c->last_grid = ta::sweep_grid_size(a, c->itemsize);
     // A hipEventRecord costs ~4 us of queue time: by default only the sweep kernel is bracketed (TA_OPT_TIMING)
     const size_t nslots = c->ring.size() / 2;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -238,6 +244,10 @@ int finish_extract(ta_ctx* c) {
         if (!c->h_small[ta::FLAG_PAIR_OVERFLOW]) {
             c->npairs = (c->feature_mask & TA_F_ADJACENCY) ? (int64_t)c->h_small[ta::NFLAGS] : 0;
             c->checked = true;
+            // more than a handful of table spills per workgroup: the next sweeps of this context use shorter tiles
+            // (results do not depend on the tile height; only the automatic height adapts, an explicit one is kept)
+            const uint64_t spills = (uint64_t)c->h_small[ta::FLAG_LDS_LABEL_SPILL] + c->h_small[ta::FLAG_LDS_PAIR_SPILL];
+            if (c->impl == 0 && c->tile_planes <= 0 && c->auto_tile_shift < 4 && spills > 8 * c->last_grid) ++c->auto_tile_shift;
             return TA_OK;
         }
         if (c->pair_log2 >= 30) break;
@@ -430,6 +440,7 @@ TA_API int ta_volume_set(ta_ctx* c, const void* host_ptr, int itemsize, const in
     TA_HIP(hipMemcpyAsync(c->owned_vol.p, host_ptr, bytes, hipMemcpyHostToDevice, c->stream));
     TA_HIP(hipStreamSynchronize(c->stream));   // the host buffer may be freed after return
     c->vol = c->owned_vol.p;
+    c->auto_tile_shift = 0;
     c->wall_records = -1;
     c->itemsize = itemsize;
     for (int k = 0; k < 3; ++k) { c->perm[k] = perm[k]; c->mdims[k] = dims[perm[k]]; }
@@ -449,6 +460,7 @@ TA_API int ta_volume_set_device(ta_ctx* c, const void* dev_ptr, int itemsize, co
     if (a0_origin < 0) return fail(TA_EINVAL, "a0_origin must be >= 0");
     if (((uintptr_t)dev_ptr % itemsize) != 0) return fail(TA_EINVAL, "device pointer is not aligned to the label type");
     c->vol = dev_ptr;
+    c->auto_tile_shift = 0;
     c->wall_records = -1;
     c->itemsize = itemsize;
     for (int k = 0; k < 3; ++k) { c->perm[k] = k; c->mdims[k] = buf_dims[k]; }
