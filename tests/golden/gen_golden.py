@@ -69,6 +69,44 @@ def config1():
     print("config1: %d labels, %d pairs, %d walls" % (len(labels), ints["pair_lo"].size, len(wkeys)))
 
 
+def config1_round2():
+    """Config C1 again, the methods added in round 2 (SURVEY.md §8f-3 and the per-label surface area): expected outputs
+    from the oracle's restatement of the reference's loops -- the per-pair bounding-box crops + two 18-connectivity
+    dilations of wall_voxels_between_two_cells (SIA:759-806), the 6-stencil of voxel_first_layer (SIA:1024-1046), the
+    exact medoid of find_wall_median_voxel (SIA:1499-1585).  Wall voxels are stored per pair as count + SHA-256 of the
+    int32 (3, N) coordinate array in np.where order (the arrays themselves would be ~2 MB)."""
+    c = synth.CONFIGS["C1"]
+    vol = synth.voronoi_labels(c["dims"], c["n_cells"], c["seed"], np.dtype(c["dtype"]))
+    vs = synth.PARITY_VOXELSIZE
+    sia = OracleSIA(vol, ignoredlabels=0, return_type=DICT, background=1, voxelsize=vs)
+    labels = sia.labels()
+    area_real, area_vox = sia.surface_area(labels, real=True), sia.surface_area(labels, real=False)
+    layer = sia.voxel_first_layer(keep_background=True)
+    walls = sia.wall_voxels_per_cells_pairs()                 # every neighbouring pair, background included
+    wkeys = sorted(walls)
+    counts, digests, medians = [], [], []
+    from oracle.sia_oracle import find_wall_median_voxel
+    for k in wkeys:
+        xyz = np.ascontiguousarray(np.asarray(walls[k]).astype(np.int32))
+        counts.append(xyz.shape[1])
+        digests.append(np.frombuffer(hashlib.sha256(xyz.tobytes()).digest(), dtype=np.uint8))
+        medians.append(find_wall_median_voxel(np.asarray(walls[k]).T) if 0 < xyz.shape[1] <= 100 and xyz.shape[1] != 3 else -1)   # (3 points: a 3x3 array, the orientation of which the reference guesses)
+    epi = sorted(sia.wall_voxels_per_cells_pairs(only_epidermis=True))
+    out = dict(
+        volume_sha256=np.frombuffer(hashlib.sha256(vol.tobytes()).digest(), dtype=np.uint8),
+        labels=np.asarray(labels),
+        surface_area_real=np.asarray([area_real[l] for l in labels]),
+        surface_area_voxel=np.asarray([area_vox[l] for l in labels]),
+        first_layer_sha256=np.frombuffer(hashlib.sha256(np.ascontiguousarray(layer).tobytes()).digest(), dtype=np.uint8),
+        first_layer_dtype=np.asarray(str(layer.dtype)), first_layer_nonzero=np.asarray(int(np.count_nonzero(layer))),
+        wall_pairs=np.asarray(wkeys, dtype=np.int64).reshape(-1, 2), wall_voxel_count=np.asarray(counts, dtype=np.int64),
+        wall_voxel_sha256=np.stack(digests), wall_median_index=np.asarray(medians, dtype=np.int64),
+        epidermis_wall_pairs=np.asarray(epi, dtype=np.int64).reshape(-1, 2),
+    )
+    np.savez_compressed(os.path.join(HERE, "config1_round2.npz"), **out)
+    print("config1_round2: %d labels, %d wall pairs (%d voxels), %d epidermis pairs" % (len(labels), len(wkeys), sum(counts), len(epi)))
+
+
 def adversarial():
     """Tiny volumes for the edge cases of SURVEY.md §4(3); inputs are stored with the outputs."""
     rng = np.random.default_rng(123)
@@ -130,5 +168,6 @@ def docstring_case():
 
 if __name__ == "__main__":
     config1()
+    config1_round2()
     adversarial()
     docstring_case()

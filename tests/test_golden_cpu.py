@@ -75,3 +75,55 @@ def test_adversarial_fixtures_match_oracles():
         want = dict((k, z[n + "__" + k]) for k in ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces"))
         assert_same_accumulators(onepass.extract(vol), want, n + " numpy")
         assert_same_accumulators(onepass_c.extract(vol), want, n + " C")
+
+
+# ---- round-2 fixture: surface areas, first layer, wall voxels, wall medians of config C1 -------------------------------
+@pytest.fixture(scope="module")
+def c1r2():
+    return np.load(os.path.join(GOLD, "config1_round2.npz"))
+
+
+def test_round2_fixture_belongs_to_the_same_volume(c1, c1r2):
+    assert np.array_equal(c1r2["volume_sha256"], c1["volume_sha256"]) and np.array_equal(c1r2["labels"], c1["labels"])
+    # every face-adjacent pair of the integer fixture is a wall pair (18-connectivity finds edge contacts on top)
+    faces = set(zip(c1["pair_lo"].tolist(), c1["pair_hi"].tolist()))
+    walls = set(map(tuple, c1r2["wall_pairs"].tolist()))
+    assert faces <= walls and (c1r2["wall_voxel_count"] > 0).all()
+
+
+def test_surface_area_from_golden_integers(c1, c1r2):
+    """Extraction.surface_faces (product host code) on the golden face counts -> the golden per-label surface areas the
+    oracle got by summing the reference's wall areas one wall at a time."""
+    x = Extraction.from_arrays(tuple(c1["shape"]), dict((k, c1[k]) for k in c1.files))
+    labels = c1r2["labels"]
+    faces = x.surface_faces(labels)                     # [n][3] faces per axis
+    vs = c1["voxelsize"]
+    face_area = np.array([vs[1] * vs[2], vs[0] * vs[2], vs[0] * vs[1]])
+    np.testing.assert_allclose(faces.sum(axis=1), c1r2["surface_area_voxel"], rtol=0, atol=0)
+    np.testing.assert_allclose(faces @ face_area, c1r2["surface_area_real"], rtol=1e-12)
+
+
+def test_wall_medians_of_the_product_on_golden_walls(c1_volume, c1r2):
+    """geometry._find_wall_median_voxel (exact medoid, the reference's <= 100 point branch) on walls rebuilt by brute force
+    must pick the golden indices."""
+    from tissue_analysis_amd.geometry import _find_wall_median_voxel
+    vol = c1_volume
+    checked = 0
+    for (a, b), n, want in zip(c1r2["wall_pairs"].tolist(), c1r2["wall_voxel_count"].tolist(), c1r2["wall_median_index"].tolist()):
+        if want < 0 or checked >= 25:
+            continue
+        # the pair's wall voxels by brute force over the 18 offsets, np.where order
+        ma, mb = vol == a, vol == b
+        pad = np.pad(mb, 1); pada = np.pad(ma, 1)
+        near_b = np.zeros_like(ma); near_a = np.zeros_like(ma)
+        for da in (-1, 0, 1):
+            for db in (-1, 0, 1):
+                for dc in (-1, 0, 1):
+                    if 0 < abs(da) + abs(db) + abs(dc) < 3:
+                        s = (slice(1 + da, 1 + da + vol.shape[0]), slice(1 + db, 1 + db + vol.shape[1]), slice(1 + dc, 1 + dc + vol.shape[2]))
+                        near_b |= pad[s]; near_a |= pada[s]
+        xyz = np.array(np.where((ma & near_b) | (mb & near_a)))
+        assert xyz.shape[1] == n, (a, b)
+        assert _find_wall_median_voxel(xyz.T) == want, (a, b)
+        checked += 1
+    assert checked >= 10
