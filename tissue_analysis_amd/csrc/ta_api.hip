@@ -81,6 +81,7 @@ struct ta_ctx {
     // adjacency
     DevBuf pkeys, pfaces, out_keys, out_faces, small;   // small: flags[NFLAGS] | cursor | maxlabel
     DevBuf hot_rows;                                    // [workgroups][16] private rows of the hot label
+    DevBuf sort_buf;                                    // scratch of ta_adjacency_get's device sort (kept between calls)
     DevBuf wall_counts;                                 // wall voxels: per-chunk record counts, then offsets
     int64_t wall_records = -1;                          // result of the last ta_wall_voxels_count, -1 = none
     double wall_ms = 0.0;
@@ -324,7 +325,7 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     c->owned_vol.release(); c->own_sums.release(); c->own_boxes.release();
     c->pkeys.release(); c->pfaces.release(); c->out_keys.release(); c->out_faces.release();
     c->small.release();
-    c->hot_rows.release();
+    c->hot_rows.release(); c->sort_buf.release();
     c->wall_counts.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -788,20 +789,29 @@ TA_API int ta_adjacency_get(ta_ctx* c, uint32_t* lo, uint32_t* hi, uint64_t* fac
     if ((rc = finish_extract(c)) != TA_OK) return rc;
     const uint64_t n = (uint64_t)c->npairs;
     if (!c->host_pairs_ready) {
-        std::vector<uint64_t> k, f;
-        std::vector<uint32_t> order;
-        try { k.resize(n); f.resize(n * 3); order.resize(n); c->h_keys.resize(n); c->h_faces.resize(n * 3); }
+        try { c->h_keys.resize(n); c->h_faces.resize(n * 3); }
         catch (...) { return fail(TA_ENOMEM, "out of host memory"); }
         if (n) {
-            TA_HIP(hipMemcpyAsync(k.data(), c->out_keys.p, n * 8, hipMemcpyDeviceToHost, c->stream));
-            TA_HIP(hipMemcpyAsync(f.data(), c->out_faces.p, n * 24, hipMemcpyDeviceToHost, c->stream));
-            TA_HIP(hipStreamSynchronize(c->stream));
-        }
-        std::iota(order.begin(), order.end(), 0u);
-        std::sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return k[x] < k[y]; });
-        for (uint64_t i = 0; i < n; ++i) {
-            c->h_keys[i] = k[order[i]];
-            for (int d = 0; d < 3; ++d) c->h_faces[3 * i + d] = f[3ull * order[i] + d];
+            // sorted by (lo, hi) on the device: stable radix sort of the keys with the record index as value, then a gather
+            // of the face counts (a std::sort of ~10^5 records used to cost more than the sweep)
+            if (n >= (1ull << 32)) return fail(TA_EINVAL, "too many pairs (%llu)", (unsigned long long)n);
+            const uint64_t temp_bytes = ta::pairs_sort_temp_bytes(n);
+            const uint64_t kb = n * 8, ib = (n * 4 + 15) & ~15ull;
+            DevBuf& buf = c->sort_buf;
+            if ((rc = buf.reserve(2 * kb + 2 * ib + n * 24 + temp_bytes + 64)) != TA_OK) return rc;
+            char* p = (char*)buf.p;
+            uint64_t* k0 = (uint64_t*)p; p += kb;
+            uint64_t* k1 = (uint64_t*)p; p += kb;
+            uint32_t* i0 = (uint32_t*)p; p += ib;
+            uint32_t* i1 = (uint32_t*)p; p += ib;
+            uint64_t* fo = (uint64_t*)p; p += n * 24;
+            uint64_t* ks = nullptr;
+            hipError_t e = hipMemcpyAsync(k0, c->out_keys.p, kb, hipMemcpyDeviceToDevice, c->stream);
+            if (e == hipSuccess) e = ta::launch_pairs_sort(c->stream, k0, k1, i0, i1, (const uint64_t*)c->out_faces.p, n, p, temp_bytes, &ks, fo);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->h_keys.data(), ks, kb, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(c->h_faces.data(), fo, n * 24, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+            if (e != hipSuccess) return fail(TA_EHIP, "adjacency sort: %s", hipGetErrorString(e));
         }
         c->host_pairs_ready = true;
     }

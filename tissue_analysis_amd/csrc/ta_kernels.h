@@ -45,6 +45,10 @@ hipError_t launch_wall_group_by_pair(hipStream_t s, const uint32_t* pairs, const
                                      uint64_t* keys1, uint32_t* index0, uint32_t* index1, void* temp, uint64_t temp_bytes,
                                      int key_bits_lo, uint32_t* pairs_out, int32_t* coords_out);
 
+uint64_t pairs_sort_temp_bytes(uint64_t n);
+hipError_t launch_pairs_sort(hipStream_t s, uint64_t* keys0, uint64_t* keys1, uint32_t* index0, uint32_t* index1, const uint64_t* faces,
+                             uint64_t n, void* temp, uint64_t temp_bytes, uint64_t** keys_sorted, uint64_t* faces_out);
+
 // kernels_basic.hip (continued)
 void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3], int64_t a_begin,
                   int64_t a_count, const int32_t* seeds_dev, const int32_t grid[3],
