@@ -62,6 +62,20 @@ class Extraction(object):
         b = self.bbox[label]
         return tuple(slice(int(b[d]), int(b[3 + d])) for d in range(3))
 
+    def bbox_slices_upto(self, top):
+        """[bbox_slices(1), ..., bbox_slices(top)] in one pass (python ints from two .tolist() calls)."""
+        top = min(int(top), self.max_label)
+        rows = self.bbox[1:top + 1].tolist()
+        have = (self.count[1:top + 1] > 0).tolist()
+        return [(slice(b[0], b[3]), slice(b[1], b[4]), slice(b[2], b[5])) if h else None for b, h in zip(rows, have)]
+
+    def neighbor_lists(self, labels):
+        """{label: ascending list of its face neighbours} for many labels at once."""
+        ptr, dst, _ = self._adjacency_csr()
+        flat, p = dst.tolist(), ptr.tolist()
+        n = len(p) - 1
+        return dict((l, flat[p[l]:p[l + 1]] if 0 <= l < n else []) for l in labels)
+
     # ------------------------------------------------------------------ moments
     def volumes(self, labels):
         return self.count[np.asarray(labels, dtype=np.int64)].astype(np.float64)

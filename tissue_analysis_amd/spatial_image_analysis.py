@@ -228,7 +228,7 @@ class AbstractSpatialImageAnalysis(object):
         if self._bbox is None:
             present = self._x.present()
             top = int(present.max()) if present.size else 0
-            self._bbox = [self._x.bbox_slices(l) for l in range(1, top + 1)]
+            self._bbox = self._x.bbox_slices_upto(top)
         return self._bbox
 
     def boundingbox(self, labels=None, real=False):
@@ -281,7 +281,7 @@ class AbstractSpatialImageAnalysis(object):
             boxes = self.boundingbox()
             if self.return_type in (NPLIST, LIST):
                 boxes = dict((i + 1, b) for i, b in enumerate(boxes))   # SIA:642-645, as written
-            self._neighbors = dict((l, self._x.neighbors_of(int(l))) for l in boxes)
+            self._neighbors = self._x.neighbor_lists([int(l) for l in boxes])
         if min_contact_area is None:
             return self._neighbors
         return self._filter_with_area(self._neighbors, min_contact_area, real_area)
@@ -345,7 +345,14 @@ class AbstractSpatialImageAnalysis(object):
 
     def wall_areas(self, neighbors=None, real=True):
         if neighbors is None:
-            neighbors = self.neighbors()
+            # every wall of every label: one pass over the sweep's pair list instead of one cell_wall_area call per label
+            # (same dictionary: the walls (l, n), n > l, of the labels l that neighbors() has as keys)
+            keys = np.fromiter(self.neighbors().keys(), dtype=np.int64)
+            x = self._x
+            sel = np.isin(x.pair_lo.astype(np.int64), keys)
+            faces = x.pair_faces[sel].astype(np.float64)
+            area = faces.dot(self.get_voxel_face_surface().astype(np.float64)) if real else faces.sum(axis=1)
+            return dict(zip(zip(x.pair_lo[sel].tolist(), x.pair_hi[sel].tolist()), area.tolist()))
         areas = {}
         for label_id, lneighbors in neighbors.items():
             neigh = [n for n in lneighbors if n > label_id]
