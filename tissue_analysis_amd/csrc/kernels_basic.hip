@@ -133,13 +133,13 @@ __device__ __forceinline__ void publish_small(const uint32_t* small, uint32_t* p
     }
 }
 
-__global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64_t* out_keys,
-                                                            uint64_t* out_faces, uint32_t* cursor) {
+__device__ __forceinline__ void pairs_collect_block(const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces,
+                                                    uint32_t* cursor, const uint32_t block) {
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t block_base;
     const uint64_t cap = (uint64_t)pt.mask + 1;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint64_t lo = (uint64_t)blockIdx.x * (256 * COLLECT_PER_THREAD);
+    const uint64_t lo = (uint64_t)block * (256 * COLLECT_PER_THREAD);
     // the thread's keys are read ONCE, all loads in flight together (coalesced 8-byte reads), and kept in registers
     uint64_t k[COLLECT_PER_THREAD];
     uint32_t mine = 0;
@@ -179,6 +179,11 @@ __global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64
         pt.keys[h] = EMPTY_KEY;                              // leave the table clean for the next call
         pt.faces[3 * h + 0] = 0; pt.faces[3 * h + 1] = 0; pt.faces[3 * h + 2] = 0;
     }
+}
+
+__global__ void __launch_bounds__(256) pairs_collect_kernel(PairTable pt, uint64_t* out_keys,
+                                                            uint64_t* out_faces, uint32_t* cursor) {
+    pairs_collect_block(pt, out_keys, out_faces, cursor, blockIdx.x);
 }
 
 void launch_pairs_collect(hipStream_t s, const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces,
@@ -347,22 +352,23 @@ void launch_pairs_clear(hipStream_t s, const PairTable& pt) {
 // ------------------------------------------------------------------------------------------
 // Fold the per-workgroup private rows of the hot label (ta_sweep_common.h: flush_tables) into its
 // global row.  Row = 128 bytes: sums u64[NSUM] | boxes i32[NBOX] | padding.
-__global__ void __launch_bounds__(256) hot_reduce_kernel(const uint64_t* __restrict__ rows, uint32_t nrows,
-                                                         const void* vol, int itemsize, int64_t corner,
-                                                         uint64_t* sums, int32_t* boxes, uint32_t max_label,
-                                                         const uint32_t* small, uint32_t* publish, int nwords) {
+struct HotFold {                      // what the fold of the private hot-label rows needs
+    const uint64_t* rows; uint32_t nrows;
+    const void* vol; int itemsize; int64_t corner;
+    uint64_t* sums; int32_t* boxes; uint32_t max_label;
+};
+
+__device__ __forceinline__ void hot_reduce_block(const HotFold& H, const uint32_t block, const uint32_t nblocks) {
     __shared__ uint64_t part[256];
-    // last kernel of a step without adjacency: the sweep's flags are final, block 0 mirrors them to the host
-    if (publish && blockIdx.x == 0) publish_small(small, publish, nwords, (int)threadIdx.x);
-    const uint32_t hot = itemsize == 2 ? (uint32_t)((const uint16_t*)vol)[corner] : ((const uint32_t*)vol)[corner];
-    if (hot > max_label) return;                           // the sweep has raised FLAG_RANGE already
+    const uint32_t hot = H.itemsize == 2 ? (uint32_t)((const uint16_t*)H.vol)[H.corner] : ((const uint32_t*)H.vol)[H.corner];
+    if (hot > H.max_label) return;                         // the sweep has raised FLAG_RANGE already
     const int col = threadIdx.x & (HOTW - 1), lanegrp = threadIdx.x / HOTW;          // 16 row-lanes per block
     const bool is_sum = col < NSUM;
     int64_t acc = is_sum ? 0 : (int64_t)INT32_MAX;
-    for (uint32_t r = blockIdx.x * (256 / HOTW) + lanegrp; r < nrows; r += gridDim.x * (256 / HOTW)) {
-        if (is_sum) acc += (int64_t)rows[(uint64_t)r * HOTW + col];
+    for (uint32_t r = block * (256 / HOTW) + lanegrp; r < H.nrows; r += nblocks * (256 / HOTW)) {
+        if (is_sum) acc += (int64_t)H.rows[(uint64_t)r * HOTW + col];
         else {
-            const int32_t v = reinterpret_cast<const int32_t*>(rows + (uint64_t)r * HOTW + NSUM)[col - NSUM];
+            const int32_t v = reinterpret_cast<const int32_t*>(H.rows + (uint64_t)r * HOTW + NSUM)[col - NSUM];
             acc = v < acc ? v : acc;
         }
     }
@@ -374,18 +380,51 @@ __global__ void __launch_bounds__(256) hot_reduce_kernel(const uint64_t* __restr
             if (is_sum) acc += v;
             else acc = v < acc ? v : acc;
         }
-        if (is_sum) { if (acc) atomicAdd((unsigned long long*)&sums[(uint64_t)hot * NSUM + col], (unsigned long long)acc); }
-        else atomicMin(&boxes[(uint64_t)hot * NBOX + (col - NSUM)], (int32_t)acc);
+        if (is_sum) { if (acc) atomicAdd((unsigned long long*)&H.sums[(uint64_t)hot * NSUM + col], (unsigned long long)acc); }
+        else atomicMin(&H.boxes[(uint64_t)hot * NBOX + (col - NSUM)], (int32_t)acc);
     }
+}
+
+__global__ void __launch_bounds__(256) hot_reduce_kernel(HotFold H, const uint32_t* small, uint32_t* publish, int nwords) {
+    // last kernel of a step without adjacency: the sweep's flags are final, block 0 mirrors them to the host
+    if (publish && blockIdx.x == 0) publish_small(small, publish, nwords, (int)threadIdx.x);
+    hot_reduce_block(H, blockIdx.x, gridDim.x);
+}
+
+// With adjacency the fold rides along with the collect: one launch (the first `collect_blocks` blocks collect, the rest
+// fold), one kernel boundary less per step.
+__global__ void __launch_bounds__(256) pairs_collect_hot_kernel(PairTable pt, uint64_t* out_keys, uint64_t* out_faces,
+                                                                uint32_t* cursor, uint32_t collect_blocks, HotFold H) {
+    if (blockIdx.x < collect_blocks) pairs_collect_block(pt, out_keys, out_faces, cursor, blockIdx.x);
+    else hot_reduce_block(H, blockIdx.x - collect_blocks, gridDim.x - collect_blocks);
+}
+
+static HotFold hot_fold(const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows) {
+    HotFold H;
+    H.rows = hot_rows; H.nrows = nrows; H.vol = a.vol; H.itemsize = itemsize;
+    H.corner = (int64_t)a.first_owned * a.n1 * a.n2; H.sums = a.sums; H.boxes = a.boxes; H.max_label = a.max_label;
+    return H;
+}
+
+static uint32_t hot_fold_blocks(uint32_t nrows) {
+    uint32_t blocks = (nrows + 15) / 16;
+    return blocks > 128 ? 128u : blocks;
+}
+
+void launch_pairs_collect_hot(hipStream_t s, const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces, uint32_t* cursor,
+                              const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows) {
+    const uint64_t cap = (uint64_t)pt.mask + 1;
+    const uint64_t per_block = 256 * COLLECT_PER_THREAD;
+    const uint32_t cb = (uint32_t)((cap + per_block - 1) / per_block);
+    hipLaunchKernelGGL(pairs_collect_hot_kernel, dim3(cb + hot_fold_blocks(nrows)), dim3(256), 0, s, pt, out_keys, out_faces,
+                       cursor, cb, hot_fold(a, itemsize, hot_rows, nrows));
 }
 
 void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows,
                        uint32_t* publish, int nwords) {
     if (!hot_rows || nrows == 0) return;
-    uint32_t blocks = (nrows + 15) / 16;
-    if (blocks > 128) blocks = 128;
-    hipLaunchKernelGGL(hot_reduce_kernel, dim3(blocks), dim3(256), 0, s, hot_rows, nrows, a.vol, itemsize,
-                       (int64_t)a.first_owned * a.n1 * a.n2, a.sums, a.boxes, a.max_label, a.flags, publish, nwords);
+    hipLaunchKernelGGL(hot_reduce_kernel, dim3(hot_fold_blocks(nrows)), dim3(256), 0, s, hot_fold(a, itemsize, hot_rows, nrows),
+                       a.flags, publish, nwords);
 }
 
 // ------------------------------------------------------------------------------------------

@@ -207,11 +207,14 @@ int run_extract(ta_ctx* c) {
     // more (every block then waits for its own stores before it can count itself done: 29 -> 44 us) than the copy.
     uint32_t* mirror = c->h_small_dev;
     bool published = false;
-    if (hot_rows) {
-        ta::launch_hot_reduce(c->stream, a, c->itemsize, hot_rows, (uint32_t)nwg, adj ? nullptr : mirror, SMALL_WORDS);
-        published = !adj && mirror;
+    if (hot_rows && !adj) {
+        ta::launch_hot_reduce(c->stream, a, c->itemsize, hot_rows, (uint32_t)nwg, mirror, SMALL_WORDS);
+        published = mirror != nullptr;
     }
-    if (adj)
+    if (adj && hot_rows)             // the fold of the hot-label rows rides along with the collect: one launch
+        ta::launch_pairs_collect_hot(c->stream, a.pairs, (uint64_t*)c->out_keys.p, (uint64_t*)c->out_faces.p, cursor_dev(c),
+                                     a, c->itemsize, hot_rows, (uint32_t)nwg);
+    else if (adj)
         ta::launch_pairs_collect(c->stream, a.pairs, (uint64_t*)c->out_keys.p, (uint64_t*)c->out_faces.p, cursor_dev(c));
     if (c->timing >= 2) TA_HIP(hipEventRecord(c->ev[3], c->stream));
     if (!published)

@@ -21,6 +21,8 @@ void launch_pairs_pack_shared(hipStream_t s, const PairTable& pt, const uint64_t
                               int64_t lo, int64_t hi, uint64_t* block, uint64_t cap, uint64_t npairs_bound);
 void launch_pairs_insert_blocks(hipStream_t s, const PairTable& pt, const uint64_t* blocks, int nblocks,
                                 uint64_t cap, uint32_t* flags);
+void launch_pairs_collect_hot(hipStream_t s, const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces, uint32_t* cursor,
+                              const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows);
 void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows,
                        uint32_t* publish = nullptr, int nwords = 0);
 void launch_relabel(hipStream_t s, void* vol, int itemsize, uint64_t n, const uint32_t* lut, uint32_t lut_len);
