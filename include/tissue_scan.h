@@ -62,8 +62,9 @@ extern "C" {
                                  with the sweep: the two cross-check each other on the GPU) */
 #define TA_OPT_TILE_PLANES 2  /* planes of memory axis 0 walked by one workgroup (tuning)          */
 #define TA_OPT_PAIR_SLOTS  3  /* log2 of the device adjacency hash capacity (0 = automatic)       */
-#define TA_OPT_TIMING      4  /* HIP events per extraction (an event record costs ~4 us of queue time):
-                               * 0 none, 1 = around the sweep kernel (default), 2 = also the step's begin / end */
+#define TA_OPT_TIMING      4  /* HIP events per extraction: 0 none, 1 = begin / end of the sweep kernel (default; they ride on
+                               * the kernel's own launch, hipExtLaunchKernelGGL: no packet of their own on the queue),
+                               * 2 = also the step's begin / end (two event records, ~4 us of queue time each)      */
 #define TA_OPT_TIMING_RING 5  /* sweep durations kept for ta_timing_series: the last N extractions, N in [1,4096]
                                * (default 1); setting it drains the stream and starts a new series             */
 

@@ -27,6 +27,8 @@
 // k | b << 10 | a << 14} (k = end column of the run = column of the right voxel).
 #include "ta_sweep_common.h"
 
+#include <hip/hip_ext.h>
+
 namespace ta {
 
 #ifndef TA_XCD_CHUNK
@@ -783,29 +785,33 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_
     scan_kernel_body<T, VPL, RB, false, MOM2, EDGE>(A, sp, wg0);
 }
 
+// ev_start / ev_stop (optional): HIP events attached to the launches themselves (hipExtLaunchKernelGGL) -- they carry the
+// dispatch's own begin / end timestamps, and cost no separate event-record packet (~4 us each) on the queue.
 template <typename T, int VPL, int RB, bool ADJ, bool MOM2>
-static void launch_scan_tt(hipStream_t s, const SweepArgs& a) {
+static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const ScanSplit sp = scan_split<VPL, RB>(a, (int)sizeof(T));
     if (sp.nbands == 0 || a.n1 <= 0 || a.n2 <= 0) return;
     const uint32_t n_in = sp.fc * sp.fb * sp.nbands;
     const uint32_t n_ed = (sp.tiles_c * sp.tiles_b - sp.fc * sp.fb) * sp.nbands;
     const dim3 block(WAVES * 64);
+    hipEvent_t in0 = ev_start, in1 = n_ed ? nullptr : ev_stop;              // interior launch
+    hipEvent_t ed0 = n_in ? nullptr : ev_start, ed1 = ev_stop;              // edge launch
     if (ADJ) {
-        if (n_in) hipLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, a, sp, 0u);
-        if (n_ed) hipLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, a, sp, n_in);
+        if (n_in) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
+        if (n_ed) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
     } else {
-        if (n_in) hipLaunchKernelGGL((scan_noadj_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, a, sp, 0u);
-        if (n_ed) hipLaunchKernelGGL((scan_noadj_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, a, sp, n_in);
+        if (n_in) hipExtLaunchKernelGGL((scan_noadj_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
+        if (n_ed) hipExtLaunchKernelGGL((scan_noadj_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
     }
 }
 
 template <typename T, int VPL, int RB>
-static void launch_scan_t(hipStream_t s, const SweepArgs& a, uint32_t fm) {
+static void launch_scan_t(hipStream_t s, const SweepArgs& a, uint32_t fm, hipEvent_t e0, hipEvent_t e1) {
     const bool adj = fm & 16u, mom2 = fm & 8u;
-    if (adj && mom2)       launch_scan_tt<T, VPL, RB, true, true>(s, a);
-    else if (adj && !mom2) launch_scan_tt<T, VPL, RB, true, false>(s, a);
-    else if (!adj && mom2) launch_scan_tt<T, VPL, RB, false, true>(s, a);
-    else                   launch_scan_tt<T, VPL, RB, false, false>(s, a);
+    if (adj && mom2)       launch_scan_tt<T, VPL, RB, true, true>(s, a, e0, e1);
+    else if (adj && !mom2) launch_scan_tt<T, VPL, RB, true, false>(s, a, e0, e1);
+    else if (!adj && mom2) launch_scan_tt<T, VPL, RB, false, true>(s, a, e0, e1);
+    else                   launch_scan_tt<T, VPL, RB, false, false>(s, a, e0, e1);
 }
 
 uint64_t sweep_grid_size(const SweepArgs& a, int itemsize) {
@@ -817,9 +823,9 @@ uint64_t sweep_grid_size(const SweepArgs& a, int itemsize) {
 int sweep_default_tile_planes(bool adjacency) { return adjacency ? 24 : 16; }
 int sweep_max_tile_planes() { return MAX_TILE_PLANES; }
 
-void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask) {
-    if (itemsize == 2) launch_scan_t<uint16_t, 8, 2>(s, a, feature_mask);
-    else               launch_scan_t<uint32_t, 4, TA_RB32>(s, a, feature_mask);
+void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask, hipEvent_t ev_start, hipEvent_t ev_stop) {
+    if (itemsize == 2) launch_scan_t<uint16_t, 8, 2>(s, a, feature_mask, ev_start, ev_stop);
+    else               launch_scan_t<uint32_t, 4, TA_RB32>(s, a, feature_mask, ev_start, ev_stop);
 }
 
 }  // namespace ta

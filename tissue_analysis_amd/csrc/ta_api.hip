@@ -197,10 +197,16 @@ int run_extract(ta_ctx* c) {
         c->table_clean = true;
     }
     ta::launch_init_accumulators(c->stream, c->sums, c->boxes, nlabels, flags_dev(c), cursor_dev(c), hot_rows);
-    if (ev_a) TA_HIP(hipEventRecord(ev_a, c->stream));
-    if (c->impl == 1) ta::launch_naive(c->stream, a, c->itemsize, c->feature_mask);
-    else              ta::launch_scan(c->stream, a, c->itemsize, c->feature_mask);
-    if (ev_b) TA_HIP(hipEventRecord(ev_b, c->stream));           // the sweep kernel alone (what the roofline is quoted on)
+    // the sweep kernel alone (what the roofline is quoted on): the two events ride on the sweep's own launches
+    // (begin / end timestamps of the dispatch, no event-record packets on the queue); the naive kernel gets plain records
+    const bool own_dims = c->mdims[0] - c->first_owned > 0 && c->mdims[1] > 0 && c->mdims[2] > 0;
+    if (c->impl == 1 || !own_dims) {
+        if (ev_a) TA_HIP(hipEventRecord(ev_a, c->stream));
+        if (c->impl == 1) ta::launch_naive(c->stream, a, c->itemsize, c->feature_mask);
+        if (ev_b) TA_HIP(hipEventRecord(ev_b, c->stream));
+    } else {
+        ta::launch_scan(c->stream, a, c->itemsize, c->feature_mask, ev_a, ev_b);
+    }
     // Without adjacency the LAST kernel of the step (the hot-row fold) mirrors the flag words into host-mapped memory
     // itself: no device-to-host copy (a blit kernel and a queue barrier) at the end of the step.  With adjacency the pair
     // count is final only when the collect kernel has ended; letting its last block publish it was measured and costs

@@ -57,7 +57,9 @@ void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3],
                   const int64_t* ell_dev);
 
 // kernels_scan.hip -- the sweep
-void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);
+// ev_start / ev_stop: optional HIP events that receive the begin of the first and the end of the last sweep launch
+void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask, hipEvent_t ev_start = nullptr,
+                 hipEvent_t ev_stop = nullptr);
 uint64_t sweep_grid_size(const SweepArgs& a, int itemsize);   // workgroups of any of the sweep kernels
 int sweep_default_tile_planes(bool adjacency);
 int sweep_max_tile_planes();
