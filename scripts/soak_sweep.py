@@ -1,6 +1,6 @@
 """One long randomised comparison of the sweep with the C oracle (GPU box; not part of the test suite):
 
-    PYTHONPATH=. python scripts/soak_sweep.py [examples] [seed]
+    PYTHONPATH=. python scripts/soak_sweep.py [examples] [seed] [progress file] [first case]
 
 Random shapes / dtypes / label sets / layouts / tile heights (0 = the default) / feature masks, bigger and blockier
 than tests/test_gpu_property.py draws them.  Prints the first mismatch and exits 1, or a summary."""
@@ -20,7 +20,7 @@ KEYS = {0: ["count", "bbox", "sum1"], 8: ["sum2"], 16: ["pair_lo", "pair_hi", "p
 done = 0
 for it in range(n):
     dtype = [np.uint16, np.uint32][rng.integers(0, 2)]
-    shape = (int(rng.integers(1, 40)), int(rng.integers(1, 70)), int(rng.choice([1, 3, 8, 17, 64, 130, 256, 257, 300, 512, 520, 768, 1030])))
+    shape = (int(rng.integers(1, 40)), int(rng.integers(1, 70)), int(rng.choice([1, 3, 4, 8, 12, 17, 64, 68, 130, 256, 257, 260, 300, 512, 520, 768, 1000, 1030])))
     top = 65535 if dtype == np.uint16 else int(rng.choice([70000, 200000, 1 << 20, 1 << 22]))       # (dense per-label rows: 2^28 labels would be 28 GB of them)
     nlab = int(rng.integers(1, 40))
     ids = np.unique(rng.integers(0, top + 1, size=nlab)).astype(dtype)
@@ -36,6 +36,8 @@ for it in range(n):
     vol = np.asfortranarray(v) if rng.random() < 0.25 else v
     tp = int(rng.choice([0, 0, 1, 2, 5, 16, 24, 32, 64]))
     mask = int(rng.choice([31, 31, 23, 15, 7, 3, 1, 17, 19, 27]))
+    if it < int(sys.argv[4] if len(sys.argv) > 4 else 0):                # (replay: skip to a case, same random stream)
+        continue
     if len(sys.argv) > 3:                                # progress file: the case about to run
         with open(sys.argv[3], "a") as fh:
             fh.write("it=%d shape=%s dtype=%s tp=%d mask=0x%x block=%s nlab=%d top=%d\n" % (it, vol.shape, vol.dtype.name, tp, mask, block, ids.size, top))

@@ -159,3 +159,21 @@ def test_repeated_sweeps_of_a_spilling_volume_adapt_the_tile_height(gpu_ctx):
         ms.append(gpu_ctx.timing()["ms_sweep"])
     assert spills[0] > 0 and spills[-1] < spills[0] // 4, spills
     assert ms[-1] < ms[0], ms
+
+
+@pytest.mark.parametrize("shape,dtype", [((1, 1, 68), np.uint32), ((3, 1, 64), np.uint16), ((2, 5, 260), np.uint32), ((4, 17, 1000), np.uint32),
+                                         ((2, 3, 8), np.uint16), ((5, 18, 520), np.uint16), ((1, 68, 1), np.uint32)])
+def test_partial_tiles_of_volumes_with_aligned_rows(gpu_ctx, shape, dtype):
+    """Rows of a multiple of 16 bytes that are not a multiple of the tile: the partial tiles run the PADDED kernel --
+    interior-style loads from clamped addresses, filler written over what lies outside (waves entirely below the last
+    row, lanes entirely right of the last column; a (1, 68, 1) array is one row of 68 in memory)."""
+    rng = np.random.default_rng(sum(shape))
+    vol = random_blocks(shape, 9, int(rng.integers(1, 99)), dtype, block=(2, 2, 7))
+    want = onepass_c.extract(vol)
+    for features in (_capi.F_ALL, 0x0f):
+        got = run(gpu_ctx, vol, 0, features=features)
+        for k in ("count", "bbox", "sum1", "sum2"):
+            assert np.array_equal(got[k], want[k]), (shape, hex(features), k)
+        if features & _capi.F_ADJACENCY:
+            for k in ("pair_lo", "pair_hi", "pair_faces"):
+                assert np.array_equal(got[k], want[k]), (shape, k)

@@ -46,7 +46,7 @@ def _check_pinned(hipcc, verbose=False):
     subprocess.check_call(cmd, cwd=OBJDIR)
     bases = {}
     for line in open(os.path.join(CSRC, "kernels_scan.hip")):
-        m = re.match(r"#define TA_PIN_(ADJ|MOM) (\d+)", line)
+        m = re.match(r"#define TA_PIN_(ADJ_PAD|MOM_PAD|ADJ|MOM) (\d+)", line)
         if m:
             bases[m.group(1)] = int(m.group(2))
     reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
@@ -66,18 +66,22 @@ def _check_pinned(hipcc, verbose=False):
                 continue
             if re.search(r"scan_(noadj_)?kernelI\w*Lb1EEEvNS_9SweepArgs", func):
                 continue              # edge kernels issue no hand-pinned loads: any register is theirs
-            if "scan_noadj_kernel" in func:
+            if "scan_noadj_pad_kernel" in func:
+                ranges = [bases["MOM_PAD"]]
+            elif "scan_pad_kernel" in func:
+                ranges = [bases["ADJ_PAD"]]
+            elif "scan_noadj_kernel" in func:
                 ranges = [bases["MOM"]]
             elif "scan_kernel" in func:
                 ranges = [bases["ADJ"]]
             else:
-                ranges = list(bases.values())      # a device function: callable from either
+                ranges = list(bases.values())      # a device function: callable from any of them
             for m in reg.finditer(t.split(";")[0]):
                 lo = int(m.group(1) or m.group(2)); hi = int(m.group(1) or m.group(3))
                 if any(hi >= b and lo < b + 21 for b in ranges):      # (21 pinned with adjacency, 16 without: the wider check is safe)
                     bad.append("%s:%d: %s" % (func, ln, t))
                     break
-    if bad or not bases:
+    if bad or len(bases) != 4:
         raise RuntimeError("compiler-allocated VGPRs reach the hand-pinned registers in kernels_scan.hip:\n  %s"
                            % "\n  ".join(bad[:10]))
 

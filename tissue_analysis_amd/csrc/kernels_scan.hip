@@ -311,6 +311,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // pinned register; the build checks the generated code (tissue_analysis_amd/build.py).
 #define TA_CAP_ADJ 100
 #define TA_CAP_MOM 72
+// the PADDED kernels (partial tiles of a volume whose rows are 16-byte aligned: interior-style loads, edge-style
+// semantics) carry more state: with adjacency 116 + 21 = 137 (three waves per SIMD), without 100 + 16 = 116 (four)
+#define TA_PIN_ADJ_PAD 120
+#define TA_PIN_MOM_PAD 104
+#define TA_CAP_ADJ_PAD 116
+#define TA_CAP_MOM_PAD 100
 template <int BASE> struct Pin;
 template <> struct Pin<104> {
     template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
@@ -336,6 +342,36 @@ template <> struct Pin<104> {
                          :: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v104\n" "v_mov_b32 %1, v105\n" "v_mov_b32 %2, v106\n" "v_mov_b32 %3, v107\n" "v_mov_b32 %4, v108\n" "v_mov_b32 %5, v109\n" "v_mov_b32 %6, v110\n" "v_mov_b32 %7, v111\n" "v_mov_b32 %8, v112\n" "v_mov_b32 %9, v113\n" "v_mov_b32 %10, v114\n" "v_mov_b32 %11, v115\n" "v_mov_b32 %12, v116\n" 
+                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
+                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
+                         :: "memory");
+        }
+    }
+};
+template <> struct Pin<120> {
+    template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
+        if (Q == 0) asm volatile("global_load_dwordx4 v[120:123], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
+        else if (Q == 1) asm volatile("global_load_dwordx4 v[124:127], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
+        else if (Q == 2) asm volatile("global_load_dwordx4 v[128:131], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
+        else if (Q == 3) asm volatile("global_load_dwordx4 v[132:135], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
+        else asm volatile("global_load_dwordx4 v[136:139], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
+    }
+    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t voff, const void* sbase) {
+        if (sizeof(T) == 4 && RB == 4) asm volatile("global_load_dword v140, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
+        if (sizeof(T) == 4 && RB != 4) asm volatile("global_load_dword v132, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
+        if (sizeof(T) != 4 && RB == 4) asm volatile("global_load_ushort v140, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
+        if (sizeof(T) != 4 && RB != 4) asm volatile("global_load_ushort v132, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
+    }
+    template <int RB> static __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {
+        if (RB == 4) {
+            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v120\n" "v_mov_b32 %1, v121\n" "v_mov_b32 %2, v122\n" "v_mov_b32 %3, v123\n" "v_mov_b32 %4, v124\n" "v_mov_b32 %5, v125\n" "v_mov_b32 %6, v126\n" "v_mov_b32 %7, v127\n" "v_mov_b32 %8, v128\n" "v_mov_b32 %9, v129\n" "v_mov_b32 %10, v130\n" "v_mov_b32 %11, v131\n" "v_mov_b32 %12, v132\n" "v_mov_b32 %13, v133\n" "v_mov_b32 %14, v134\n" "v_mov_b32 %15, v135\n" "v_mov_b32 %16, v136\n" "v_mov_b32 %17, v137\n" "v_mov_b32 %18, v138\n" "v_mov_b32 %19, v139\n" "v_mov_b32 %20, v140\n" 
+                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
+                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
+                           "=&v"(raw[RB > 2 ? 2 : 0].x), "=&v"(raw[RB > 2 ? 2 : 0].y), "=&v"(raw[RB > 2 ? 2 : 0].z), "=&v"(raw[RB > 2 ? 2 : 0].w),
+                           "=&v"(raw[RB > 3 ? 3 : 0].x), "=&v"(raw[RB > 3 ? 3 : 0].y), "=&v"(raw[RB > 3 ? 3 : 0].z), "=&v"(raw[RB > 3 ? 3 : 0].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
+                         :: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v120\n" "v_mov_b32 %1, v121\n" "v_mov_b32 %2, v122\n" "v_mov_b32 %3, v123\n" "v_mov_b32 %4, v124\n" "v_mov_b32 %5, v125\n" "v_mov_b32 %6, v126\n" "v_mov_b32 %7, v127\n" "v_mov_b32 %8, v128\n" "v_mov_b32 %9, v129\n" "v_mov_b32 %10, v130\n" "v_mov_b32 %11, v131\n" "v_mov_b32 %12, v132\n" 
                          : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
                            "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
                          :: "memory");
@@ -378,7 +414,11 @@ __device__ __forceinline__ void unpack_strip(const u32x4& x, uint32_t (&dst)[VPL
     }
 }
 
-template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, typename LDS>
+// EDGE: the tile may hold positions outside the volume (they carry the filler INVALID_LABEL) and may lack a row above / a
+// column to the left.  PINB: 0 = plain guarded loads (volumes whose rows are not 16-byte aligned), else the first of the
+// hand-pinned registers the plane in flight lands in.  EDGE with PINB != 0 is the PADDED variant: interior-style loads from
+// clamped addresses, the positions outside the volume overwritten with the filler when the plane lands.
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, typename LDS>
 __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* kp, LDS& S, const int lane, const int w,
                                           const uint32_t c_tile0, const uint32_t b_tile0,
                                           const int32_t p_lo, const int32_t p_hi) {
@@ -395,7 +435,16 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     const bool has_left = ADJ && c_tile0 > 0;
     const bool has_prev = ADJ && p_lo > 0;
     const uint32_t lane_c = (uint32_t)lane * VPL;
-    const uint32_t lane_off = lane_c * (uint32_t)sizeof(T);
+    constexpr bool PAD = EDGE && PINB != 0;
+    // PADDED: a lane whose strip lies past the end of the row (rows hold a multiple of VPL voxels: a strip is inside or
+    // outside as a whole) loads the tile's first strip instead; a row past the last one loads the wave's first row (the
+    // last row of the volume when the whole wave is outside)
+    const bool lane_in = !PAD || c0g + VPL <= n2;
+    const uint32_t lane_off = (lane_in ? lane_c : 0u) * (uint32_t)sizeof(T);
+    const int64_t b_base = PAD && b_wave0 >= n1 ? n1 - 1 : b_wave0;
+    bool row_in[RB];
+#pragma unroll
+    for (int r = 0; r < RB; ++r) row_in[r] = !PAD || b_wave0 + r < n1;
 
     // The working set of a lane: the RB x VPL voxels of the CURRENT plane, the strip of the row above, the voxel to
     // the left.  The previous plane is never kept: its faces with the current one are taken at the moment the new
@@ -432,20 +481,47 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     //    to the left reads its own first row / column instead: those compares can never fire, so the hot loop does
     //    not test has_up / has_left at all.  One running pointer walks the planes.
     const uint32_t rowbytes = (uint32_t)(n2 * (int64_t)sizeof(T));
-    const uint32_t left_off = (uint32_t)(lane & (RB - 1)) * rowbytes;    // (the VGPR offset of a load is unsigned)
+    const uint32_t left_off = (uint32_t)(PAD && b_wave0 + (lane & (RB - 1)) >= n1 ? 0 : (lane & (RB - 1))) * rowbytes;    // (the VGPR offset of a load is unsigned)
     const int64_t plane_bytes = plane * (int64_t)sizeof(T);
-    const char* next_row0 = reinterpret_cast<const char*>(vol + (int64_t)(has_prev ? p_lo - 1 : p_lo) * plane + b_wave0 * n2 + c_tile0);
+    const char* next_row0 = reinterpret_cast<const char*>(vol + (int64_t)(has_prev ? p_lo - 1 : p_lo) * plane + b_base * n2 + c_tile0);
     auto issue_plane = [&]() {                            // issues the plane at `next_row0` and steps it
         const char* row0 = next_row0;
         next_row0 += plane_bytes;
-        using P = Pin<ADJ ? TA_PIN_ADJ : TA_PIN_MOM>;
+        using P = Pin<PINB ? PINB : TA_PIN_ADJ>;
         P::template issue_strip<0>(lane_off, row0);
-        P::template issue_strip<1>(lane_off, row0 + rowbytes);
-        if (RB > 2) { P::template issue_strip<2>(lane_off, row0 + 2 * (int64_t)rowbytes); P::template issue_strip<3>(lane_off, row0 + 3 * (int64_t)rowbytes); }
+        P::template issue_strip<1>(lane_off, row_in[1] ? row0 + rowbytes : row0);
+        if (RB > 2) {
+            P::template issue_strip<2>(lane_off, row_in[RB > 2 ? 2 : 0] ? row0 + 2 * (int64_t)rowbytes : row0);
+            P::template issue_strip<3>(lane_off, row_in[RB > 3 ? 3 : 0] ? row0 + 3 * (int64_t)rowbytes : row0);
+        }
         if (ADJ) {       // (without adjacency nobody looks at the row above or the voxel to the left)
-            if (RB > 2) P::template issue_strip<4>(lane_off, has_up ? row0 - rowbytes : row0);
-            else        P::template issue_strip<2>(lane_off, has_up ? row0 - rowbytes : row0);
+            // (PADDED, the whole wave past the last row: row0 is the last row of the volume; the row "above" it is not asked for)
+            const bool up_there = has_up && (!PAD || b_wave0 < n1);
+            if (RB > 2) P::template issue_strip<4>(lane_off, up_there ? row0 - rowbytes : row0);
+            else        P::template issue_strip<2>(lane_off, up_there ? row0 - rowbytes : row0);
             P::template issue_voxel<T, RB>(left_off, has_left ? row0 - sizeof(T) : row0);
+        }
+    };
+
+    // PADDED: what landed for positions outside the volume is overwritten with the filler; a REAL voxel equal to the
+    // filler (0xFFFFFFFF in a uint32 volume: above any max_label) is reported like the plain edge loads report it
+    auto pad_plane = [&](uint32_t (&nw)[RB][VPL], uint32_t (&nup)[VPL], uint32_t& nl) {
+        if constexpr (PAD) {
+            if (sizeof(T) == 4) {
+                uint32_t mx = 0u;
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int j = 0; j < VPL; ++j) mx = max(mx, (row_in[r] && lane_in) ? nw[r][j] : 0u);
+                bad = bad || mx == INVALID_LABEL;
+            }
+#pragma unroll
+            for (int r = 0; r < RB; ++r)
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) nw[r][j] = (row_in[r] && lane_in) ? nw[r][j] : INVALID_LABEL;
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) nup[j] = (has_up && lane_in && b_wave0 < n1) ? nup[j] : INVALID_LABEL;
+            nl = (has_left && lane < RB && b_wave0 + lane < n1) ? nl : INVALID_LABEL;
         }
     };
 
@@ -514,15 +590,21 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     u32x4 nraw[RB], nup_raw;                                                  // interior tiles: the plane just read back
 #pragma unroll
     for (int j = 0; j < VPL; ++j) { up[j] = INVALID_LABEL; nxt_up[j] = INVALID_LABEL; }
-    if constexpr (EDGE) {
+    if constexpr (PINB == 0) {
         if (has_prev) load_rows(p_lo - 1, cur);
         load_rows(p_lo, nxt); load_halo(p_lo, nxt_up, nxt_leftv);
     } else {
         if (has_prev) {
             issue_plane();
-            Pin<ADJ ? TA_PIN_ADJ : TA_PIN_MOM>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+            Pin<PINB>::template landed<RB>(nraw, nup_raw, nxt_leftv);
 #pragma unroll
             for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], cur[r]);
+            if constexpr (PAD) {
+                uint32_t dump_up[VPL], dump_l = 0u;
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) dump_up[j] = 0u;
+                pad_plane(cur, dump_up, dump_l);
+            }
         }
         issue_plane();
     }
@@ -543,7 +625,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #ifdef TA_STAMPS
         const uint64_t t4 = TA_T();
 #endif
-        if constexpr (EDGE) {
+        if constexpr (PINB == 0) {
             if (ADJ && (p > p_lo || has_prev)) plane_faces(nxt);
 #pragma unroll
             for (int r = 0; r < RB; ++r)
@@ -554,17 +636,22 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             for (int j = 0; j < VPL; ++j) up[j] = nxt_up[j];
             if (p + 1 < p_hi) { load_rows(p + 1, nxt); load_halo(p + 1, nxt_up, nxt_leftv); }
         } else {
-            Pin<ADJ ? TA_PIN_ADJ : TA_PIN_MOM>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+            Pin<PINB ? PINB : TA_PIN_ADJ>::template landed<RB>(nraw, nup_raw, nxt_leftv);
             if (p + 1 < p_hi) issue_plane();
-            uint32_t nw[RB][VPL];
+            uint32_t nw[RB][VPL], nup[VPL];
 #pragma unroll
             for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], nw[r]);
+            if (ADJ) unpack_strip<T, VPL>(nup_raw, nup);
+            pad_plane(nw, nup, nxt_leftv);
             if (ADJ && (p > p_lo || has_prev)) plane_faces(nw);
 #pragma unroll
             for (int r = 0; r < RB; ++r)
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) cur[r][j] = nw[r][j];
-            if (ADJ) unpack_strip<T, VPL>(nup_raw, up);
+            if (ADJ) {
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) up[j] = nup[j];
+            }
             leftv = nxt_leftv;
         }
         if (p == p_lo) first_label = __builtin_amdgcn_readfirstlane(cur[0][0]);
@@ -690,7 +777,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 // bounds), the partial tiles of the last tile column / tile row (or everything, when the rows are not 16-byte
 // aligned) to the edge kernel.  Both write the same tables; `wg0` numbers the edge kernel's workgroups after
 // the interior kernel's (private hot-label rows).
-struct ScanSplit { uint32_t tiles_c, tiles_b, fc, fb, nbands; };
+struct ScanSplit { uint32_t tiles_c, tiles_b, fc, fb, nbands, padded; };
 
 template <int VPL, int RB>
 static ScanSplit scan_split(const SweepArgs& a, int itemsize) {
@@ -702,10 +789,11 @@ static ScanSplit scan_split(const SweepArgs& a, int itemsize) {
     const bool fast = a.vec_ok && a.n2 * itemsize * (int64_t)RB < (1ll << 31);
     s.fc = fast ? (uint32_t)(a.n2 / TC) : 0u; s.fb = fast ? (uint32_t)(a.n1 / TB) : 0u;
     if (s.fc == 0 || s.fb == 0) { s.fc = 0; s.fb = 0; }
+    s.padded = fast ? 1u : 0u;         // the partial tiles go to the padded kernel (rows are 16-byte aligned), else to the plain edge kernel
     return s;
 }
 
-template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE>
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB>
 __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanSplit& sp, const uint32_t wg0) {
     constexpr int NW = MOM2 ? 6 : 2;
     constexpr int TC = 64 * VPL, TB = WAVES * RB;
@@ -765,7 +853,7 @@ __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanS
     __syncthreads();
 
     if (p_lo < p_hi)
-        wave_scan<T, VPL, RB, ADJ, MOM2, EDGE>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
+        wave_scan<T, VPL, RB, ADJ, MOM2, EDGE, PINB>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
     __syncthreads();
     // (everything the flush needs is re-read -- arguments from the kernarg segment, the tile origin from LDS --
     //  rather than kept in scarce SGPRs across the sweep)
@@ -775,14 +863,23 @@ __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanS
                                       (TA_HOT_ADJ || !ADJ) ? hot_label_of<T>(Ac) : 0u, wg_);
 }
 
-// (two entry points only because the VGPR budget is an attribute and must be a literal)
+// (several entry points only because the VGPR budget is an attribute and must be a literal)
 template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ))) scan_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
-    scan_kernel_body<T, VPL, RB, true, MOM2, EDGE>(A, sp, wg0);
+    scan_kernel_body<T, VPL, RB, true, MOM2, EDGE, EDGE ? 0 : TA_PIN_ADJ>(A, sp, wg0);
 }
 template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_MOM))) scan_noadj_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
-    scan_kernel_body<T, VPL, RB, false, MOM2, EDGE>(A, sp, wg0);
+    scan_kernel_body<T, VPL, RB, false, MOM2, EDGE, EDGE ? 0 : TA_PIN_MOM>(A, sp, wg0);
+}
+// the partial tiles of a volume with 16-byte aligned rows: hand-issued loads like the interior tiles, filler like the edge tiles
+template <typename T, int VPL, int RB, bool MOM2>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ_PAD))) scan_pad_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+    scan_kernel_body<T, VPL, RB, true, MOM2, true, TA_PIN_ADJ_PAD>(A, sp, wg0);
+}
+template <typename T, int VPL, int RB, bool MOM2>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_MOM_PAD))) scan_noadj_pad_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+    scan_kernel_body<T, VPL, RB, false, MOM2, true, TA_PIN_MOM_PAD>(A, sp, wg0);
 }
 
 // ev_start / ev_stop (optional): HIP events attached to the launches themselves (hipExtLaunchKernelGGL) -- they carry the
@@ -798,10 +895,12 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_star
     hipEvent_t ed0 = n_in ? nullptr : ev_start, ed1 = ev_stop;              // edge launch
     if (ADJ) {
         if (n_in) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
-        if (n_ed) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
+        if (n_ed && sp.padded) hipExtLaunchKernelGGL((scan_pad_kernel<T, VPL, RB, MOM2>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
+        else if (n_ed) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
     } else {
         if (n_in) hipExtLaunchKernelGGL((scan_noadj_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
-        if (n_ed) hipExtLaunchKernelGGL((scan_noadj_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
+        if (n_ed && sp.padded) hipExtLaunchKernelGGL((scan_noadj_pad_kernel<T, VPL, RB, MOM2>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
+        else if (n_ed) hipExtLaunchKernelGGL((scan_noadj_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
     }
 }
 
