@@ -177,3 +177,28 @@ def test_partial_tiles_of_volumes_with_aligned_rows(gpu_ctx, shape, dtype):
         if features & _capi.F_ADJACENCY:
             for k in ("pair_lo", "pair_hi", "pair_faces"):
                 assert np.array_equal(got[k], want[k]), (shape, k)
+
+
+@pytest.mark.parametrize("shape,dtype", [((9, 11, 23), np.uint16), ((6, 20, 301), np.uint32), ((5, 33, 1030), np.uint16), ((3, 7, 1), np.uint32)])
+def test_adopted_buffers_with_unaligned_rows_take_the_guarded_loads(shape, dtype):
+    """A device buffer the library did not allocate itself has no slack behind it: with rows that are not a multiple of 16 bytes
+    it runs the plain edge kernel (guarded scalar loads) -- the same results as the 16-byte loads an uploaded copy gets."""
+    import torch
+    vol = random_blocks(shape, 25, 77, dtype, block=(2, 3, 9))
+    want = onepass_c.extract(vol)
+    signed = {np.uint16: torch.int16, np.uint32: torch.int32}[dtype]
+    t = torch.from_numpy(vol.view({np.uint16: np.int16, np.uint32: np.int32}[dtype]).copy()).to("cuda:0")
+    assert t.dtype == signed
+    ctx = _capi.Context(0)
+    try:
+        ctx.set_volume_device(t.data_ptr(), vol.dtype.itemsize, vol.shape, keep=t)
+        for features in (_capi.F_ALL, 0x0f):
+            ctx.extract(features, int(vol.max()))
+            count, bbox, sum1, sum2 = ctx.labels()
+            assert np.array_equal(count, want["count"]) and np.array_equal(bbox, want["bbox"])
+            assert np.array_equal(sum1, want["sum1"]) and np.array_equal(sum2, want["sum2"])
+            if features & _capi.F_ADJACENCY:
+                lo, hi, faces = ctx.adjacency()
+                assert np.array_equal(lo, want["pair_lo"]) and np.array_equal(hi, want["pair_hi"]) and np.array_equal(faces, want["pair_faces"])
+    finally:
+        ctx.close()

@@ -436,11 +436,13 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     const bool has_prev = ADJ && p_lo > 0;
     const uint32_t lane_c = (uint32_t)lane * VPL;
     constexpr bool PAD = EDGE && PINB != 0;
-    // PADDED: a lane whose strip lies past the end of the row (rows hold a multiple of VPL voxels: a strip is inside or
-    // outside as a whole) loads the tile's first strip instead; a row past the last one loads the wave's first row (the
-    // last row of the volume when the whole wave is outside)
-    const bool lane_in = !PAD || c0g + VPL <= n2;
-    const uint32_t lane_off = (lane_in ? lane_c : 0u) * (uint32_t)sizeof(T);
+    // PADDED: a lane whose strip lies past the end of the row loads the tile's first strip instead (a strip that straddles
+    // the end is loaded where it is: the few bytes past the row are the next row's, or the slack behind the library's own
+    // volume buffer); a row past the last one loads the wave's first row (the last row of the volume when the whole wave
+    // is outside).  `nin`: how many voxels of the lane's strip are inside the row.
+    const int64_t nin64 = n2 - c0g;
+    const uint32_t nin = !PAD ? (uint32_t)VPL : (nin64 <= 0 ? 0u : (nin64 >= VPL ? (uint32_t)VPL : (uint32_t)nin64));
+    const uint32_t lane_off = (nin ? lane_c : 0u) * (uint32_t)sizeof(T);
     const int64_t b_base = PAD && b_wave0 >= n1 ? n1 - 1 : b_wave0;
     bool row_in[RB];
 #pragma unroll
@@ -512,15 +514,15 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #pragma unroll
                 for (int r = 0; r < RB; ++r)
 #pragma unroll
-                    for (int j = 0; j < VPL; ++j) mx = max(mx, (row_in[r] && lane_in) ? nw[r][j] : 0u);
+                    for (int j = 0; j < VPL; ++j) mx = max(mx, (row_in[r] && (uint32_t)j < nin) ? nw[r][j] : 0u);
                 bad = bad || mx == INVALID_LABEL;
             }
 #pragma unroll
             for (int r = 0; r < RB; ++r)
 #pragma unroll
-                for (int j = 0; j < VPL; ++j) nw[r][j] = (row_in[r] && lane_in) ? nw[r][j] : INVALID_LABEL;
+                for (int j = 0; j < VPL; ++j) nw[r][j] = (row_in[r] && (uint32_t)j < nin) ? nw[r][j] : INVALID_LABEL;
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) nup[j] = (has_up && lane_in && b_wave0 < n1) ? nup[j] : INVALID_LABEL;
+            for (int j = 0; j < VPL; ++j) nup[j] = (has_up && (uint32_t)j < nin && b_wave0 < n1) ? nup[j] : INVALID_LABEL;
             nl = (has_left && lane < RB && b_wave0 + lane < n1) ? nl : INVALID_LABEL;
         }
     };
@@ -789,7 +791,7 @@ static ScanSplit scan_split(const SweepArgs& a, int itemsize) {
     const bool fast = a.vec_ok && a.n2 * itemsize * (int64_t)RB < (1ll << 31);
     s.fc = fast ? (uint32_t)(a.n2 / TC) : 0u; s.fb = fast ? (uint32_t)(a.n1 / TB) : 0u;
     if (s.fc == 0 || s.fb == 0) { s.fc = 0; s.fb = 0; }
-    s.padded = fast ? 1u : 0u;         // the partial tiles go to the padded kernel (rows are 16-byte aligned), else to the plain edge kernel
+    s.padded = fast ? 1u : 0u;         // the partial tiles go to the padded kernel (vector loads allowed), else to the plain edge kernel
     return s;
 }
 
