@@ -776,9 +776,10 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 }
 
 // Tiles of a volume: `fc` x `fb` full tiles per plane band go to the interior kernel (hand-issued 16-byte loads, no
-// bounds), the partial tiles of the last tile column / tile row (or everything, when the rows are not 16-byte
-// aligned) to the edge kernel.  Both write the same tables; `wg0` numbers the edge kernel's workgroups after
-// the interior kernel's (private hot-label rows).
+// bounds); the partial tiles of the last tile column / tile row go to the PADDED kernel (the same loads from clamped
+// addresses, filler written over what lies outside) when 16-byte loads are allowed (SweepArgs::vec_ok), else everything
+// goes to the plain edge kernel (guarded scalar loads).  All write the same tables; `wg0` numbers the second launch's
+// workgroups after the interior kernel's (private hot-label rows).
 struct ScanSplit { uint32_t tiles_c, tiles_b, fc, fb, nbands, padded; };
 
 template <int VPL, int RB>
