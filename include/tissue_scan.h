@@ -65,6 +65,9 @@ extern "C" {
 #define TA_OPT_TIMING      4  /* HIP events per extraction: 0 none, 1 = begin / end of the sweep kernel (default; they ride on
                                * the kernel's own launch, hipExtLaunchKernelGGL: no packet of their own on the queue),
                                * 2 = also the step's begin / end (two event records, ~4 us of queue time each)      */
+#define TA_OPT_VOLUME_SLACK 6 /* bytes that are readable behind the volume adopted by ta_volume_set_device (reset to 0 by that
+                               * call): with >= 16 the sweep uses 16-byte loads whatever the row length -- the strip that
+                               * straddles the end of the last row reads up to 12 bytes past the volume                   */
 #define TA_OPT_TIMING_RING 5  /* sweep durations kept for ta_timing_series: the last N extractions, N in [1,4096]
                                * (default 1); setting it drains the stream and starts a new series             */
 

@@ -179,19 +179,27 @@ def test_partial_tiles_of_volumes_with_aligned_rows(gpu_ctx, shape, dtype):
                 assert np.array_equal(got[k], want[k]), (shape, k)
 
 
+@pytest.mark.parametrize("slack", [False, True], ids=["exact_buffer", "storage_with_slack"])
 @pytest.mark.parametrize("shape,dtype", [((9, 11, 23), np.uint16), ((6, 20, 301), np.uint32), ((5, 33, 1030), np.uint16), ((3, 7, 1), np.uint32)])
-def test_adopted_buffers_with_unaligned_rows_take_the_guarded_loads(shape, dtype):
-    """A device buffer the library did not allocate itself has no slack behind it: with rows that are not a multiple of 16 bytes
-    it runs the plain edge kernel (guarded scalar loads) -- the same results as the 16-byte loads an uploaded copy gets."""
+def test_adopted_buffers_with_unaligned_rows(shape, dtype, slack):
+    """A device buffer the library did not allocate itself and that ends with the volume has no slack behind it: with rows
+    that are not a multiple of 16 bytes it runs the plain edge kernel (guarded scalar loads).  A tensor that is a view of a
+    larger storage (tissue_analysis_amd.device.empty_volume makes them) tells the library so (TA_OPT_VOLUME_SLACK) and gets
+    the 16-byte loads.  Same results either way."""
     import torch
     vol = random_blocks(shape, 25, 77, dtype, block=(2, 3, 9))
     want = onepass_c.extract(vol)
-    signed = {np.uint16: torch.int16, np.uint32: torch.int32}[dtype]
-    t = torch.from_numpy(vol.view({np.uint16: np.int16, np.uint32: np.int32}[dtype]).copy()).to("cuda:0")
-    assert t.dtype == signed
+    host = torch.from_numpy(vol.view({np.uint16: np.int16, np.uint32: np.int32}[dtype]).copy())
+    if slack:
+        flat = torch.empty((vol.size + 16,), dtype=host.dtype, device="cuda:0")
+        t = flat[:vol.size].view(*vol.shape)
+        t.copy_(host)
+    else:
+        t = host.to("cuda:0")
     ctx = _capi.Context(0)
     try:
         ctx.set_volume_device(t.data_ptr(), vol.dtype.itemsize, vol.shape, keep=t)
+        assert (ctx.get_option(_capi.OPT_VOLUME_SLACK) >= 16) == slack
         for features in (_capi.F_ALL, 0x0f):
             ctx.extract(features, int(vol.max()))
             count, bbox, sum1, sum2 = ctx.labels()

@@ -18,7 +18,7 @@ F_VOLUME, F_BBOX, F_MOMENT1, F_MOMENT2, F_ADJACENCY = 1, 2, 4, 8, 16
 F_ALL = 31
 FEATURES = dict(VOLUME=F_VOLUME, BBOX=F_BBOX, MOMENT1=F_MOMENT1, MOMENT2=F_MOMENT2,
                 ADJACENCY=F_ADJACENCY)
-OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS, OPT_TIMING, OPT_TIMING_RING = 1, 2, 3, 4, 5
+OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS, OPT_TIMING, OPT_TIMING_RING, OPT_VOLUME_SLACK = 1, 2, 3, 4, 5, 6
 STREAM_LEGACY_DEFAULT = 1          # TA_STREAM_LEGACY_DEFAULT of include/tissue_scan.h
 
 # every symbol include/tissue_scan.h declares
@@ -276,6 +276,14 @@ class Context(object):
         _check(self._lib.ta_volume_set_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(itemsize),
                                               _i64x3(buf_dims), int(a0_origin), int(bool(has_low_halo))))
         self._keep = [keep]
+        # a torch tensor that is a view of a larger storage: tell the library how many bytes are readable behind it
+        try:
+            st = keep.untyped_storage()
+            end = (keep.storage_offset() + keep.numel()) * keep.element_size()
+            if keep.is_contiguous() and int(keep.data_ptr()) == int(dev_ptr) and st.nbytes() > end:
+                self.set_option(OPT_VOLUME_SLACK, int(st.nbytes() - end))
+        except AttributeError:
+            pass
 
     def max_label(self):
         v = ctypes.c_uint32(0)

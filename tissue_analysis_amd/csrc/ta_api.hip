@@ -94,6 +94,7 @@ struct ta_ctx {
     // options / state
     int impl = 0;
     int tile_planes = 0;
+    int64_t volume_slack = 0;                           // TA_OPT_VOLUME_SLACK: bytes readable behind an adopted volume
     int auto_tile_shift = 0;                            // automatic tile height halved this many times (table spills seen)
     uint64_t last_grid = 0;                             // workgroups of the last sweep
     uint32_t feature_mask = 0;
@@ -166,7 +167,8 @@ int run_extract(ta_ctx* c) {
     // 16-byte loads: rows that are 16-byte aligned, or ANY rows of a volume the library uploaded itself (unaligned 16-byte
     // global loads are legal on gfx950 -- 6.2 TB/s from dword-aligned, 4.8 TB/s from odd addresses, measured -- and the
     // strip that straddles the end of the very last row reads into the slack ta_volume_set leaves behind the buffer)
-    a.vec_ok = ((((uintptr_t)c->vol & 15) == 0) && ((a.n2 * c->itemsize) % 16 == 0)) || (c->vol == c->owned_vol.p && c->owned_vol.p);
+    a.vec_ok = ((((uintptr_t)c->vol & 15) == 0) && ((a.n2 * c->itemsize) % 16 == 0)) || (c->vol == c->owned_vol.p && c->owned_vol.p) ||
+               c->volume_slack >= 16;       // (an adopted buffer whose owner promises readable bytes behind it: TA_OPT_VOLUME_SLACK)
     a.max_label = c->max_label;
     a.sums = c->sums;
     a.boxes = c->boxes;
@@ -379,6 +381,9 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
         case TA_OPT_PAIR_SLOTS:
             if (value != 0 && (value < 4 || value > 30)) return fail(TA_EINVAL, "TA_OPT_PAIR_SLOTS must be 0 or in [4,30]");
             c->opt_pair_log2 = (int)value; return TA_OK;
+        case TA_OPT_VOLUME_SLACK:
+            if (value < 0) return fail(TA_EINVAL, "TA_OPT_VOLUME_SLACK must be >= 0");
+            c->volume_slack = value; return TA_OK;
         case TA_OPT_TIMING:
             if (value < 0 || value > 2) return fail(TA_EINVAL, "TA_OPT_TIMING must be 0, 1 or 2");
             c->timing = (int)value; return TA_OK;
@@ -406,6 +411,7 @@ TA_API int ta_ctx_get_option(ta_ctx* c, int key, int64_t* value) {
     if (!c || !value) return fail(TA_EINVAL, "NULL argument");
     switch (key) {
         case TA_OPT_IMPL: *value = c->impl; return TA_OK;
+        case TA_OPT_VOLUME_SLACK: *value = c->volume_slack; return TA_OK;
         case TA_OPT_TIMING: *value = c->timing; return TA_OK;
         case TA_OPT_TIMING_RING: *value = (int64_t)(c->ring.size() / 2); return TA_OK;
         case TA_OPT_TILE_PLANES: *value = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY); return TA_OK;
@@ -473,6 +479,7 @@ TA_API int ta_volume_set_device(ta_ctx* c, const void* dev_ptr, int itemsize, co
     if (a0_origin < 0) return fail(TA_EINVAL, "a0_origin must be >= 0");
     if (((uintptr_t)dev_ptr % itemsize) != 0) return fail(TA_EINVAL, "device pointer is not aligned to the label type");
     c->vol = dev_ptr;
+    c->volume_slack = 0;
     c->auto_tile_shift = 0;
     c->wall_records = -1;
     c->itemsize = itemsize;

@@ -22,7 +22,12 @@ def torch_context(device=0):
 def empty_volume(planes, dims, dtype, device=0):
     import torch
     tdt = getattr(torch, _TORCH_DTYPE[np.dtype(dtype).name])
-    return torch.empty((int(planes), int(dims[1]), int(dims[2])), dtype=tdt, device="cuda:%d" % device)
+    # a view of a storage with 16 elements to spare: the sweep may then use 16-byte loads whatever the row length (the
+    # strip that straddles the end of the last row reads a few bytes past the volume; _capi.Context.set_volume_device
+    # sees the slack in the tensor's storage)
+    n = int(planes) * int(dims[1]) * int(dims[2])
+    flat = torch.empty((n + 16,), dtype=tdt, device="cuda:%d" % device)
+    return flat[:n].view(int(planes), int(dims[1]), int(dims[2]))
 
 
 def synth_slab(ctx, dims, dtype, n_cells, seed, a_begin=0, a_end=None, device=0, ellipsoid=True):
