@@ -312,11 +312,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define TA_CAP_ADJ 100
 #define TA_CAP_MOM 72
 // the PADDED kernels (partial tiles of a volume whose rows are 16-byte aligned: interior-style loads, edge-style
-// semantics) carry more state: with adjacency 116 + 21 = 137 (three waves per SIMD), without 100 + 16 = 116 (four)
+// semantics) carry more state: with adjacency 116 + 21 = 137 (three waves per SIMD), without 80 + 16 = 96 (five, like the
+// interior kernel)
 #define TA_PIN_ADJ_PAD 120
-#define TA_PIN_MOM_PAD 104
+#define TA_PIN_MOM_PAD 80
 #define TA_CAP_ADJ_PAD 116
-#define TA_CAP_MOM_PAD 100
+#define TA_CAP_MOM_PAD 76
 template <int BASE> struct Pin;
 template <> struct Pin<104> {
     template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
@@ -396,6 +397,31 @@ template <> struct Pin<76> {
                          :: "memory");
         } else {
             asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v76\n" "v_mov_b32 %1, v77\n" "v_mov_b32 %2, v78\n" "v_mov_b32 %3, v79\n" "v_mov_b32 %4, v80\n" "v_mov_b32 %5, v81\n" "v_mov_b32 %6, v82\n" "v_mov_b32 %7, v83\n" 
+                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
+                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w)
+                         :: "memory");
+        }
+        (void)upr; (void)l;
+    }
+};
+template <> struct Pin<80> {
+    template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
+        if (Q == 0) asm volatile("global_load_dwordx4 v[80:83], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+        else if (Q == 1) asm volatile("global_load_dwordx4 v[84:87], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+        else if (Q == 2) asm volatile("global_load_dwordx4 v[88:91], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+        else asm volatile("global_load_dwordx4 v[92:95], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
+    }
+    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t, const void*) {}
+    template <int RB> static __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {
+        if (RB == 4) {
+            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v80\n" "v_mov_b32 %1, v81\n" "v_mov_b32 %2, v82\n" "v_mov_b32 %3, v83\n" "v_mov_b32 %4, v84\n" "v_mov_b32 %5, v85\n" "v_mov_b32 %6, v86\n" "v_mov_b32 %7, v87\n" "v_mov_b32 %8, v88\n" "v_mov_b32 %9, v89\n" "v_mov_b32 %10, v90\n" "v_mov_b32 %11, v91\n" "v_mov_b32 %12, v92\n" "v_mov_b32 %13, v93\n" "v_mov_b32 %14, v94\n" "v_mov_b32 %15, v95\n" 
+                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
+                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
+                           "=&v"(raw[RB > 2 ? 2 : 0].x), "=&v"(raw[RB > 2 ? 2 : 0].y), "=&v"(raw[RB > 2 ? 2 : 0].z), "=&v"(raw[RB > 2 ? 2 : 0].w),
+                           "=&v"(raw[RB > 3 ? 3 : 0].x), "=&v"(raw[RB > 3 ? 3 : 0].y), "=&v"(raw[RB > 3 ? 3 : 0].z), "=&v"(raw[RB > 3 ? 3 : 0].w)
+                         :: "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v80\n" "v_mov_b32 %1, v81\n" "v_mov_b32 %2, v82\n" "v_mov_b32 %3, v83\n" "v_mov_b32 %4, v84\n" "v_mov_b32 %5, v85\n" "v_mov_b32 %6, v86\n" "v_mov_b32 %7, v87\n" 
                          : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
                            "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w)
                          :: "memory");
