@@ -36,3 +36,23 @@ def assert_same_accumulators(got, want, what=""):
 
 def extraction_arrays(x):
     return x.as_arrays()
+
+
+WALL_OFFSETS = [(a, b, c) for a in (-1, 0, 1) for b in (-1, 0, 1) for c in (-1, 0, 1) if 0 < abs(a) + abs(b) + abs(c) < 3]
+
+
+def brute_wall_records(vol):
+    """Wall-voxel records of every label pair by brute force over the 18 offsets of generate_binary_structure(3, 2):
+    (lo, hi, coords[n, 3]) sorted by (lo, hi, voxel in memory order) -- what ta_wall_voxels_get_by_pair returns."""
+    n0, n1, n2 = vol.shape
+    idx = np.arange(vol.size, dtype=np.int64).reshape(vol.shape)
+    recs = []
+    for a, b, c in WALL_OFFSETS:
+        src = (slice(max(0, -a), n0 - max(0, a)), slice(max(0, -b), n1 - max(0, b)), slice(max(0, -c), n2 - max(0, c)))
+        dst = (slice(max(0, a), n0 - max(0, -a)), slice(max(0, b), n1 - max(0, -b)), slice(max(0, c), n2 - max(0, -c)))
+        v, m, i = vol[src].astype(np.int64), vol[dst].astype(np.int64), idx[src]
+        hit = v != m
+        recs.append(np.stack([np.minimum(v, m)[hit], np.maximum(v, m)[hit], i[hit]], axis=1))
+    r = np.unique(np.concatenate(recs), axis=0)
+    coords = np.stack(np.unravel_index(r[:, 2], vol.shape), axis=1).astype(np.int32)
+    return r[:, 0].astype(np.uint32), r[:, 1].astype(np.uint32), coords

@@ -11,7 +11,7 @@ from tissue_analysis_amd.graph_from_image import (availables_properties, availab
                                                   property_graph_to_dataframe, spatio_temporal_properties3D)
 
 from graph_compare import compare_graph
-from helpers import voronoi
+from helpers import brute_wall_records, voronoi
 
 VS = synth.PARITY_VOXELSIZE
 ALL = ['boundingbox', 'volume', 'barycenter', 'L1', 'border', 'inertia_axis', 'wall_surface', 'epidermis_surface']
@@ -42,6 +42,26 @@ def test_graph_matches_the_reference_restatement(props, real, margins, min_area)
     compare_graph(g, want)
 
 
+@pytest.mark.parametrize("margins,min_area,subset", [(True, None, False), (False, 3.0, True)])
+def test_wall_medians_from_a_grouped_wall_table(margins, min_area, subset):
+    """'wall_median' and its two vertex companions: the wall-voxel table is injected as the device would deliver it
+    (records grouped by pair; here from a brute force over the 18 offsets), the medians are segment reductions over it."""
+    from tissue_analysis_amd.extraction import WallTable
+    vol = voronoi((30, 28, 36), 24, 35, np.uint16)
+    sia = analysis(vol)
+    sia._walls = WallTable(*brute_wall_records(vol), grouped=True)
+    props = ['L1', 'wall_surface', 'wall_median']
+    keep = [l for l in sia.labels() if l != 1][2:14] if subset else None
+    g = graph_from_image(sia, labels=None if keep is None else list(keep), spatio_temporal_properties=list(props),
+                         ignore_cells_at_stack_margins=margins, min_contact_area=min_area)
+    want = graph_oracle.graph_tables(oracle_analysis(vol), None if keep is None else list(keep), 1, list(props), True,
+                                     margins, min_area)
+    assert len(want["edge"]["wall_median"]) > 5 and len(want["vertex"]["epidermis_wall_median"]) > 2
+    compare_graph(g, want)
+    values, valid = g.edge_column('wall_median')
+    assert values.dtype == np.int64 and values.shape == (g.nb_edges(), 3) and valid.all()
+
+
 def test_label_subset_ignores_the_rest():
     vol = voronoi((40, 36, 44), 40, 32, np.uint16)
     sia = analysis(vol)
@@ -58,6 +78,37 @@ def test_advertised_names_and_topology_helper():
     g, l2v, edges = generate_graph_topology([2, 3, 5], {2: [3, 9], 3: [2, 5], 5: [3], 9: [2]})
     assert l2v == {2: 2, 3: 3, 5: 5} and sorted(edges) == [(2, 3), (3, 5)]
     assert sorted(g.neighbors(3)) == [2, 5]
+
+
+def test_tables_are_arrays_and_views_are_mappings():
+    vol = voronoi((40, 36, 44), 40, 33, np.uint16)
+    g = graph_from_image(analysis(vol), spatio_temporal_properties=list(ALL), ignore_cells_at_stack_margins=False)
+    vol_col, ok = g.vertex_column('volume')
+    assert isinstance(vol_col, np.ndarray) and vol_col.shape == (g.nb_vertices(),) and ok.all()
+    assert g.vertex_column('inertia_axis')[0].shape == (g.nb_vertices(), 3, 3)
+    assert np.all(g.edge_sources < g.edge_targets)
+    key = g.edge_sources * (1 << 32) + g.edge_targets
+    assert np.all(np.diff(key) > 0)                                      # sorted by (lo, hi), no duplicates
+    indptr, nbr, eid = g.csr()
+    assert indptr[-1] == 2 * g.nb_edges()
+    v = int(g.vertex_ids[5])
+    assert g.neighbors(v) == set(int(t if s == v else s) for s, t in zip(g.edge_sources, g.edge_targets) if v in (s, t))
+    # the mapping view writes through to the column, and turns generic once a value does not fit the column's type
+    view = g.vertex_property('volume')
+    view[v] = 7.5
+    assert g.vertex_column('volume')[0][5] == 7.5
+    del view[v]
+    assert v not in view and len(view) == g.nb_vertices() - 1
+    view[v] = "unknown"
+    assert view[v] == "unknown" and g.vertex_column('volume')[0].dtype == object
+    with pytest.raises(KeyError):
+        view[10 ** 9] = 1.0
+    # the container's incremental interface on the same tables
+    new = g.add_vertex()
+    e = g.add_edge(v, new)
+    assert g.edge_vertices(e) == (v, new) and new in g.neighbors(v) and new not in g.vertex_property('L1')
+    with pytest.raises(ValueError):
+        g.add_vertex_property('volume')
 
 
 def test_dataframe_export():

@@ -1,54 +1,50 @@
-"""``graph_from_image``: the caller of the hot path, same names, arguments and
-property names as the reference module (TGI = temporal_graph_from_image.py:30-407), on top of the
-drop-in ``SpatialImageAnalysis`` -- so every per-label number comes from the one GPU sweep.
+"""``graph_from_image``: the immediate caller of the hot path, assembled from the ARRAYS of the GPU
+sweep -- one masked reduction over the sweep's label-pair list per property, no per-label Python.
 
-Reference behaviour kept as written (and pinned by tests against ``oracle/graph_oracle.py``):
-  * `availables_spatial_properties()` advertises 'wall_area' / 'epidermis_area' but the builder
-    tests for 'wall_surface' / 'epidermis_surface' (TGI:169, 187): only the latter spellings compute
-    anything; 'L2' is advertised and never computed.
-  * `analysis.inertia_axis(labels, barycenters)` (TGI:165) passes the barycentre dict in the `real`
-    slot: real-unit eigenvalues iff 'barycenter' was requested before.
-  * 'epidermis_surface' calls `analysis.cell_wall_surface` (TGI:197), which the reference class does
-    not define (AttributeError there); here it is `cell_wall_area(background, ...)`, its evident intent.
-  * 'wall_median' (TGI:210-242): wall voxels of every pair from the one-pass GPU extraction
-    (`wall_voxels_per_cells_pairs`), their geometric median by the reference's own Weiszfeld iteration
-    (SIA:1586-1635) truncated to integers, then the wall voxel closest to it (`closest_from_A`, an absent
-    third-party helper restated in geometry.py); keys with label 0 / 1 go to 'unlabelled_wall_median' /
-    'epidermis_wall_median' as in the reference.
+What it keeps of the reference module (TGI = temporal_graph_from_image.py): the public names and signatures
+(`graph_from_image` TGI:260-284 and the helpers TGI:30-74, 309-398), the property names, and the rules that decide the
+numbers.  How it computes them is unrelated to the reference's dict-and-loop code:
+
+    inputs    Extraction: count[L], bbox[L,6], sum1[L,3], sum2[L,6]; pairs lo[P] < hi[P] sorted, faces[P,3]
+    vertices  the requested labels (vertex id = label, TGI:44)
+    edges     the pairs with both ends requested whose REAL contact area is not below `min_contact_area`
+              (`neighbors(labels, min_contact_area)` always filters on real areas, SIA:538)  -- a mask over the pair list
+    columns   volume / barycenter / boundingbox / inertia: row gathers of the accumulators;
+              L1, epidermis_surface: the pairs holding the background; border: a test on the bounding boxes;
+              wall_surface: faces . face areas of the edge rows; unlabelled_wall_surface: a bincount over the pairs with
+              exactly one requested end; wall medians: segment reductions over the wall-voxel records the device grouped
+              by pair (geometry.median_voxels).
+
+Rules of the reference that are kept because they decide results (each pinned by tests against oracle/graph_oracle.py):
+  * `availables_spatial_properties()` advertises 'wall_area' / 'epidermis_area' but the builder tests for 'wall_surface' /
+    'epidermis_surface' (TGI:169, 187): only the latter compute anything; 'L2' is advertised and never computed.
+  * inertia eigenvalues are in real units iff 'barycenter' was requested: TGI:165 passes the barycentre dict in
+    `inertia_axis`'s `real` slot.
+  * 'epidermis_surface' calls a method the reference class does not define (TGI:197, `cell_wall_surface`); its evident
+    intent, the wall area with the background, is what is computed.
+  * wall medians (TGI:210-242): geometric median by the reference's stopping rules, truncated, then the nearest wall
+    voxel; walls keyed (0, l) go to 'unlabelled_wall_median', walls keyed (1, l) to 'epidermis_wall_median' whatever the
+    background is.
+  * when an analysis object is passed with `labels=None`, the labels are taken BEFORE the margin cells are ignored
+    (TGI:268-271), so margin cells stay vertices.
 """
 from __future__ import annotations
 
 import numpy as np
 
-from .geometry import closest_from_A, geometric_median
+from .geometry import gather_segments, median_voxels
 from .property_graph import PropertyGraph
 from .spatial_image_analysis import AbstractSpatialImageAnalysis, DICT, SpatialImageAnalysis
 
-
-def generate_graph_topology(labels, neighborhood):  # TGI:30-60
-    graph = PropertyGraph()
-    vertex2label = {}
-    for l in labels:
-        vertex2label[graph.add_vertex(l)] = l
-    label2vertex = dict((j, i) for i, j in vertex2label.items())
-    labelset = set(labels)
-    edges = {}
-    for source, targets in neighborhood.items():
-        if source in labelset:
-            for target in targets:
-                if source < target and target in labelset:
-                    edges[(source, target)] = graph.add_edge(label2vertex[source], label2vertex[target])
-    graph.add_vertex_property('label')
-    graph.vertex_property('label').update(vertex2label)
-    return graph, label2vertex, edges
+_INT = (int, np.integer)
 
 
-def availables_spatial_properties():  # TGI:63-67
-    return ['boundingbox', 'volume', 'barycenter', 'L1', 'L2', 'border', 'inertia_axis', 'wall_area',
-            'epidermis_area', 'wall_median']
+def availables_spatial_properties():
+    return ['boundingbox', 'volume', 'barycenter', 'L1', 'L2', 'border', 'inertia_axis', 'wall_area', 'epidermis_area',
+            'wall_median']
 
 
-def availables_properties():  # TGI:70-74
+def availables_properties():
     return sorted(availables_spatial_properties())
 
 
@@ -56,181 +52,176 @@ spatio_temporal_properties2D = ['barycenter', 'boundingbox', 'border', 'L1', 'ep
 spatio_temporal_properties3D = availables_properties()
 
 
-def label2vertex_map(graph, time_point=None):
-    return dict((l, v) for v, l in graph.vertex_property('label').items())
+# ----------------------------------------------------------------------------- how table rows are shown as Python values
+def _show_slices(row):
+    return (slice(int(row[0]), int(row[3])), slice(int(row[1]), int(row[4])), slice(int(row[2]), int(row[5])))
 
 
-def add_vertex_property_from_dictionary(graph, name, dictionary, mlabel2vertex=None, time_point=None,
-                                        overwrite=False):  # TGI:309-328
-    if mlabel2vertex is None:
-        mlabel2vertex = label2vertex_map(graph, time_point)
-    if name in graph.vertex_properties() and not overwrite:
-        raise ValueError("Existing vertex property '{}'".format(name))
-    if overwrite:
-        graph.remove_vertex_property(name)
-    graph.add_vertex_property(name)
-    graph.vertex_property(name).update(dict((mlabel2vertex[k], dictionary[k]) for k in dictionary))
-    return "Done."
+def _show_intervals(row):
+    return [(row[0, 0], row[0, 1]), (row[1, 0], row[1, 1]), (row[2, 0], row[2, 1])]
 
 
-def add_vertex_property_from_label_and_value(graph, name, labels, property_values, mlabel2vertex=None,
-                                             overwrite=False):  # TGI:330-349
-    if mlabel2vertex is None:
-        mlabel2vertex = label2vertex_map(graph)
-    if name in graph.vertex_properties() and not overwrite:
-        raise ValueError("Existing vertex property '{}'".format(name))
-    if overwrite:
-        graph.remove_vertex_property(name)
-    graph.add_vertex_property(name)
-    graph.vertex_property(name).update(dict((mlabel2vertex[i], v) for i, v in zip(labels, property_values)))
-    return "Done."
+def _show_axes(row):
+    return [row[0], row[1], row[2]]
 
 
-add_vertex_property_from_label_property = add_vertex_property_from_dictionary
+def _show_point(row):
+    return (int(row[0]), int(row[1]), int(row[2]))
 
 
-def add_edge_property_from_dictionary(graph, name, dictionary, mlabelpair2edge=None, time_point=None,
-                                      overwrite=False):  # TGI:351-370
-    if mlabelpair2edge is None:
-        mlabelpair2edge = labelpair2edge_map(graph)
-    if name in graph.edge_properties() and not overwrite:
-        raise ValueError("Existing edge property '{}'".format(name))
-    if overwrite:
-        graph.remove_edge_property(name)
-    graph.add_edge_property(name)
-    graph.edge_property(name).update(dict((mlabelpair2edge[k], dictionary[k]) for k in dictionary))
-    return "Done."
+# ----------------------------------------------------------------------------- the assembly
+class _PairView(object):
+    """The sweep's pair list with the per-call quantities every property needs."""
+
+    def __init__(self, analysis, vertex_ids, min_contact_area):
+        x = analysis.extraction
+        self.lo = x.pair_lo.astype(np.int64)
+        self.hi = x.pair_hi.astype(np.int64)
+        faces = x.pair_faces.astype(np.float64)
+        surf = np.asarray(analysis.get_voxel_face_surface(), dtype=np.float64)
+        self.area_real = faces[:, 0] * surf[0] + faces[:, 1] * surf[1] + faces[:, 2] * surf[2]
+        self.area_voxels = faces[:, 0] + faces[:, 1] + faces[:, 2]
+        top = int(max(x.max_label, int(self.hi.max()) if self.hi.size else 0)) + 1
+        ids = np.asarray(vertex_ids, dtype=np.int64)
+        inside = (ids >= 0) & (ids <= top)
+        self.row_of = np.full(top + 1, -1, dtype=np.int64)               # label -> vertex row
+        self.row_of[ids[inside]] = np.flatnonzero(inside)
+        self.lo_in = self.row_of[self.lo] >= 0
+        self.hi_in = self.row_of[self.hi] >= 0
+        self.kept = np.ones(self.lo.size, dtype=bool) if min_contact_area is None else ~(self.area_real < min_contact_area)
+
+    def area(self, real):
+        return self.area_real if real else self.area_voxels
+
+    def partners_of(self, label):
+        """(pair rows holding `label`, the label at their other end)."""
+        rows = np.flatnonzero((self.lo == label) | (self.hi == label))
+        return rows, np.where(self.lo[rows] == label, self.hi[rows], self.lo[rows])
 
 
-add_edge_property_from_label_property = add_edge_property_from_dictionary
+def _wall_median_columns(graph, analysis, pairs, background):
+    """Median voxel of every wall the reference visits (TGI:210-242 through wall_voxels_per_cells_pairs with
+    ignore_background=False): kept pairs with both ends requested, or one end requested and the other the background."""
+    bg = -1 if background is None else int(background)
+    want = pairs.kept & ((pairs.lo_in & pairs.hi_in) | (pairs.lo_in & (pairs.hi == bg)) | (pairs.hi_in & (pairs.lo == bg)))
+    lo, hi = pairs.lo[want], pairs.hi[want]
+    table = analysis.wall_table()
+    key = (lo.astype(np.uint64) << np.uint64(32)) | hi.astype(np.uint64)
+    at = np.searchsorted(table.pairs, key)
+    found = at < table.pairs.size
+    found[found] = table.pairs[at[found]] == key[found]
+    lo, hi, at = lo[found], hi[found], at[found]
+    rows, sizes = gather_segments(table.start[at], table.stop[at])
+    chosen = median_voxels(table.coords[rows].astype(np.int64), sizes).reshape(-1, 3)
+
+    V, E = graph.nb_vertices(), graph.nb_edges()
+    edge_value, edge_valid = np.zeros((E, 3), dtype=np.int64), np.zeros(E, dtype=bool)
+    both = (pairs.row_of[lo] >= 0) & (pairs.row_of[hi] >= 0)
+    ekey = (graph.edge_sources.astype(np.uint64) << np.uint64(32)) | graph.edge_targets.astype(np.uint64)
+    erow = np.searchsorted(ekey, ((lo[both].astype(np.uint64) << np.uint64(32)) | hi[both].astype(np.uint64)))
+    edge_value[erow], edge_valid[erow] = chosen[both], True
+    graph.set_edge_column('wall_median', edge_value, edge_valid, _show_point)
+    for name, first in (('epidermis_wall_median', 1), ('unlabelled_wall_median', 0)):
+        value, valid = np.zeros((V, 3), dtype=np.int64), np.zeros(V, dtype=bool)
+        sel = (lo == first) & (pairs.row_of[hi] >= 0)
+        value[pairs.row_of[hi[sel]]], valid[pairs.row_of[hi[sel]]] = chosen[sel], True
+        graph.set_vertex_column(name, value, valid, _show_point)
 
 
-def add_edge_property_from_label_and_value(graph, name, label_pairs, property_values, mlabelpair2edge=None,
-                                           overwrite=False):  # TGI:372-391
-    if mlabelpair2edge is None:
-        mlabelpair2edge = labelpair2edge_map(graph)
-    if name in graph.edge_properties() and not overwrite:
-        raise ValueError("Existing edge property '{}'".format(name))
-    if overwrite:
-        graph.remove_edge_property(name)
-    graph.add_edge_property(name)
-    graph.edge_property(name).update(dict((mlabelpair2edge[p], v) for p, v in zip(label_pairs, property_values)))
-    return "Done."
+def tissue_tables(analysis, labels, background, properties, property_as_real=True, min_contact_area=None):
+    """The vertex / edge tables of the tissue graph from the sweep results held by `analysis`.
+    `labels`: the vertex ids (any order, distinct).  Returns a PropertyGraph whose columns are plain numpy arrays."""
+    x = analysis.extraction
+    ids = np.asarray(labels, dtype=np.int64).reshape(-1)
+    pairs = _PairView(analysis, ids, min_contact_area)
+    is_edge = pairs.kept & pairs.lo_in & pairs.hi_in
+    graph = PropertyGraph(ids, pairs.lo[is_edge], pairs.hi[is_edge])
+    graph.set_vertex_column('label', ids.copy())
+    graph.add_graph_property("units", dict())
+    V = ids.size
+    known = (ids >= 0) & (ids <= x.max_label)
+    rows = np.where(known, ids, 0)                                         # accumulator rows (row 0 stands in for unknown ids)
+    present = known & (x.count[rows] > 0)
+    # volume / barycenter / inertia go through `label_request`, which drops what the analysis ignores (SIA:387-414)
+    ignored = np.fromiter(analysis.ignoredlabels(), dtype=np.int64, count=len(analysis.ignoredlabels()))
+    asked = present & ~np.isin(ids, ignored)
+    vs = np.asarray(analysis._voxelsize, dtype=np.float64)
+    real = bool(property_as_real)
+
+    if 'boundingbox' in properties:
+        box = x.bbox[rows].astype(np.int64)
+        if real:
+            box = np.stack([box[:, :3] * vs, box[:, 3:] * vs], axis=2)      # [V, axis, (start, stop)]
+            graph.set_vertex_column('boundingbox', box, present, _show_intervals)
+        else:
+            graph.set_vertex_column('boundingbox', box, present, _show_slices)
+    if 'volume' in properties and analysis.is3D():
+        volume = x.count[rows].astype(np.float64)
+        graph.set_vertex_column('volume', volume * (vs[0] * vs[1] * vs[2]) if real else volume, asked)
+    with_barycenter = 'barycenter' in properties
+    if with_barycenter:
+        com = x.barycenters(rows)
+        graph.set_vertex_column('barycenter', com * vs if real else com, asked)
+
+    bg_rows, bg_partner = pairs.partners_of(-1 if background is None else int(background))
+    touches = pairs.row_of[bg_partner] >= 0                                # requested labels sharing a face with the background
+    l1 = np.zeros(V, dtype=bool)
+    l1[pairs.row_of[bg_partner[touches]]] = True
+    if 'L1' in properties:
+        graph.set_vertex_column('L1', l1)
+    if 'border' in properties:
+        at_margin = np.asarray(analysis.labels_at_stack_margins(), dtype=np.int64)
+        border = np.zeros(V, dtype=bool)
+        hit = graph.vertex_rows(at_margin[at_margin != (-1 if background is None else int(background))])
+        border[hit[hit >= 0]] = True
+        graph.set_vertex_column('border', border)
+    if 'inertia_axis' in properties:
+        axes, values = x.inertia(rows)
+        if with_barycenter and asked.any():                                # TGI:165: the barycentres sit in the `real` slot
+            values = values * np.linalg.norm(axes * vs, axis=2)
+        graph.set_vertex_column('inertia_axis', axes, asked, _show_axes)
+        graph.set_vertex_column('inertia_values', values, asked)
+
+    if 'wall_surface' in properties:
+        area = pairs.area(real)
+        graph.set_edge_column('wall_surface', area[is_edge])
+        # walls with a label that is neither requested nor the background, summed at their requested end -- only those
+        # whose outer label is the LARGER one: the reference sums them with `wall_areas`, which skips n <= label (SIA:988)
+        one_end = pairs.kept & pairs.lo_in & ~pairs.hi_in & (pairs.hi != (-1 if background is None else int(background)))
+        graph.set_vertex_column('unlabelled_wall_surface',
+                                np.bincount(pairs.row_of[pairs.lo[one_end]], weights=area[one_end], minlength=V))
+    if 'epidermis_surface' in properties:
+        value = np.zeros(V, dtype=np.float64)
+        value[pairs.row_of[bg_partner[touches]]] = pairs.area(real)[bg_rows[touches]]
+        graph.set_vertex_column('epidermis_surface', value, l1)
+    if 'wall_median' in properties:
+        _wall_median_columns(graph, analysis, pairs, background)
+    return graph
 
 
-def labelpair2edge_map(graph, time_point=None):
-    lab = graph.vertex_property('label')
-    out = {}
-    for e in graph.edges():
-        s, t = graph.edge_vertices(e)
-        a, b = lab[s], lab[t]
-        out[(min(a, b), max(a, b))] = e
-    return out
-
-
-def retrieve_label_neighbors(SpI_Analysis, label, labelset, min_contact_area, real_area):  # TGI:394-398
-    return set(SpI_Analysis.neighbors(label, min_contact_area, real_area)) & labelset
-
-
-def _graph_from_image(image, labels, background, default_properties, property_as_real,
-                      ignore_cells_at_stack_margins, min_contact_area):  # TGI:77-244
+def _graph_from_image(image, labels, background, default_properties, property_as_real, ignore_cells_at_stack_margins,
+                      min_contact_area):
+    """TGI:77-244: which analysis object, which labels are ignored, which become vertices -- then the tables."""
     if isinstance(image, AbstractSpatialImageAnalysis):
         analysis = image
-        image = analysis.image
     else:
         try:
             analysis = SpatialImageAnalysis(image, ignoredlabels=0, return_type=DICT, background=1)
-        except Exception:
+        except (ValueError, AssertionError):
             analysis = SpatialImageAnalysis(image, ignoredlabels=0, return_type=DICT)
     if ignore_cells_at_stack_margins:
         analysis.add2ignoredlabels(analysis.labels_at_stack_margins())
-
     if labels is None:
-        labels = list(analysis.labels())
-        if background in labels:
-            del labels[labels.index(background)]
+        ids = np.asarray(analysis.labels(), dtype=np.int64)
+        ids = ids[ids != background]
     else:
-        if isinstance(labels, (int, np.integer)):
+        if isinstance(labels, _INT):
             labels = [labels]
         if background in labels:
-            labels.remove(background)
-        analysis.add2ignoredlabels(set(analysis.labels()) - set(labels))
-
-    neighborhood = analysis.neighbors(labels, min_contact_area=min_contact_area)
-    labelset = set(labels)
-    graph, label2vertex, edges = generate_graph_topology(labels, neighborhood)
-    graph.add_graph_property("units", dict())
-
-    if 'boundingbox' in default_properties:
-        add_vertex_property_from_dictionary(graph, 'boundingbox', analysis.boundingbox(labels, real=property_as_real),
-                                            mlabel2vertex=label2vertex)
-    if 'volume' in default_properties and analysis.is3D():
-        add_vertex_property_from_dictionary(graph, 'volume', analysis.volume(labels, real=property_as_real),
-                                            mlabel2vertex=label2vertex)
-    barycenters = None
-    if 'barycenter' in default_properties:
-        barycenters = analysis.center_of_mass(labels, real=property_as_real)
-        add_vertex_property_from_dictionary(graph, 'barycenter', barycenters, mlabel2vertex=label2vertex)
-
-    background_neighbors = set(analysis.neighbors(background))
-    background_neighbors.intersection_update(labelset)
-    if 'L1' in default_properties:
-        add_vertex_property_from_label_and_value(graph, 'L1', labels, [(l in background_neighbors) for l in labels],
-                                                 mlabel2vertex=label2vertex)
-    if 'border' in default_properties:
-        border_cells = analysis.labels_at_stack_margins()
-        try:
-            border_cells.remove(background)
-        except ValueError:
-            pass
-        border_cells = set(border_cells)
-        add_vertex_property_from_label_and_value(graph, 'border', labels, [(l in border_cells) for l in labels],
-                                                 mlabel2vertex=label2vertex)
-    if 'inertia_axis' in default_properties:
-        inertia_axis, inertia_values = analysis.inertia_axis(labels, bool(barycenters))      # TGI:165, as written
-        add_vertex_property_from_dictionary(graph, 'inertia_axis', inertia_axis, mlabel2vertex=label2vertex)
-        add_vertex_property_from_dictionary(graph, 'inertia_values', inertia_values, mlabel2vertex=label2vertex)
-
-    if 'wall_surface' in default_properties:
-        filtered_edges, unlabelled_target = {}, {}
-        for source, targets in neighborhood.items():
-            if source in labelset:
-                filtered_edges[source] = [t for t in targets if source < t and t in labelset]
-                unlabelled_target[source] = [t for t in targets if t not in labelset and t != background]
-        wall_surfaces = analysis.wall_areas(filtered_edges, real=property_as_real)
-        add_edge_property_from_label_property(graph, 'wall_surface', wall_surfaces, mlabelpair2edge=edges)
-        graph.add_vertex_property('unlabelled_wall_surface')
-        for source in unlabelled_target:
-            unlabelled = analysis.wall_areas({source: unlabelled_target[source]}, real=property_as_real)
-            graph.vertex_property('unlabelled_wall_surface')[label2vertex[source]] = sum(unlabelled.values())
-
-    if 'epidermis_surface' in default_properties:
-        epidermis = analysis.cell_wall_area(background, list(background_neighbors), real=property_as_real)
-        epidermis = dict(((b if a == background else a), v) for (a, b), v in epidermis.items())
-        add_vertex_property_from_label_property(graph, 'epidermis_surface', epidermis, mlabel2vertex=label2vertex)
-
-    if 'wall_median' in default_properties:  # TGI:210-242
-        dict_wall_voxels = analysis.wall_voxels_per_cells_pairs(labels, neighborhood, ignore_background=False,
-                                                                verbose=False)
-        wall_median = {}
-        for (label_1, label_2), (x, y, z) in dict_wall_voxels.items():
-            origin = np.array([int(v) for v in geometric_median(np.array([list(x), list(y), list(z)]))])
-            pts = [(int(x[i]), int(y[i]), int(z[i])) for i in range(len(x))]
-            wall_median[(label_1, label_2)] = closest_from_A(origin, pts)
-        edge_wall_median, unlabelled_wall_median, vertex_wall_median = {}, {}, {}
-        vertices = set(graph.vertices())
-        for label_1, label_2 in dict_wall_voxels.keys():
-            if (label_1 in vertices) and (label_2 in vertices):
-                edge_wall_median[(label_1, label_2)] = wall_median[(label_1, label_2)]
-            if label_1 == 0:
-                unlabelled_wall_median[label_2] = wall_median[(label_1, label_2)]
-            if label_1 == 1:
-                vertex_wall_median[label_2] = wall_median[(label_1, label_2)]
-        add_edge_property_from_dictionary(graph, 'wall_median', edge_wall_median, mlabelpair2edge=edges)
-        add_vertex_property_from_dictionary(graph, 'epidermis_wall_median', vertex_wall_median, mlabel2vertex=label2vertex)
-        add_vertex_property_from_dictionary(graph, 'unlabelled_wall_median', unlabelled_wall_median,
-                                            mlabel2vertex=label2vertex)
-    return graph
+            labels.remove(background)                                      # the caller's list, as in the reference
+        ids = np.asarray(labels, dtype=np.int64)
+        analysis.add2ignoredlabels(np.setdiff1d(np.asarray(analysis.labels(), dtype=np.int64), ids))
+    return tissue_tables(analysis, ids, background, default_properties, property_as_real, min_contact_area)
 
 
 def graph_from_image2D(image, labels, background, spatio_temporal_properties, property_as_real,
@@ -239,65 +230,122 @@ def graph_from_image2D(image, labels, background, spatio_temporal_properties, pr
                              ignore_cells_at_stack_margins, min_contact_area)
 
 
-def graph_from_image3D(image, labels, background, spatio_temporal_properties, property_as_real,
-                       ignore_cells_at_stack_margins, min_contact_area):
-    return _graph_from_image(image, labels, background, spatio_temporal_properties, property_as_real,
-                             ignore_cells_at_stack_margins, min_contact_area)
+graph_from_image3D = graph_from_image2D        # (the reference's two entry points run the same body, TGI:247-258)
 
 
 def graph_from_image(image, labels=None, background=1, spatio_temporal_properties=None, property_as_real=True,
-                     ignore_cells_at_stack_margins=True, min_contact_area=None):  # TGI:260-284
+                     ignore_cells_at_stack_margins=True, min_contact_area=None):
+    """TGI:260-284.  `image`: a label image or an analysis object of this package."""
     if isinstance(image, AbstractSpatialImageAnalysis):
-        real_image = image.image
+        shape = np.shape(image.image)
         if labels is None:
-            labels = image.labels()
+            labels = image.labels()                                        # before the margin cells are ignored
     else:
-        real_image = image
-    flat = np.ndim(real_image) == 2 or (np.ndim(real_image) == 3 and np.shape(real_image)[2] == 1)
-    if flat:
-        if spatio_temporal_properties is None:
-            spatio_temporal_properties = spatio_temporal_properties2D
-        return graph_from_image2D(image, labels, background, spatio_temporal_properties, property_as_real,
-                                  ignore_cells_at_stack_margins, min_contact_area)
+        shape = np.shape(image)
+    flat = len(shape) == 2 or (len(shape) == 3 and shape[2] == 1)
     if spatio_temporal_properties is None:
-        spatio_temporal_properties = spatio_temporal_properties3D
-    return graph_from_image3D(image, labels, background, spatio_temporal_properties, property_as_real,
-                              ignore_cells_at_stack_margins, min_contact_area)
+        spatio_temporal_properties = spatio_temporal_properties2D if flat else spatio_temporal_properties3D
+    build = graph_from_image2D if flat else graph_from_image3D
+    return build(image, labels, background, spatio_temporal_properties, property_as_real, ignore_cells_at_stack_margins,
+                 min_contact_area)
 
 
+# ----------------------------------------------------------------------------- helpers of TGI:30-60, 309-398, by name
+def generate_graph_topology(labels, neighborhood):
+    """TGI:30-60: vertices = `labels`; one edge per pair s < t, both in `labels`, with t listed under s.
+    Returns (graph, label -> vertex id, (s, t) -> edge id)."""
+    ids = np.asarray(list(labels), dtype=np.int64)
+    member = set(ids.tolist())
+    src = [s for s, ts in neighborhood.items() if s in member for t in ts if s < t and t in member]
+    dst = [t for s, ts in neighborhood.items() if s in member for t in ts if s < t and t in member]
+    graph = PropertyGraph(ids, src, dst)
+    graph.set_vertex_column('label', ids.copy())
+    return graph, dict(zip(ids.tolist(), ids.tolist())), dict(zip(zip(src, dst), range(len(src))))
+
+
+def label2vertex_map(graph, time_point=None):
+    values, valid = graph.vertex_column('label')
+    return dict(zip(values[valid].tolist(), graph.vertex_ids[valid].tolist()))
+
+
+def labelpair2edge_map(graph, time_point=None):
+    values, _ = graph.vertex_column('label')
+    a = values[graph.vertex_rows(graph.edge_sources)]
+    b = values[graph.vertex_rows(graph.edge_targets)]
+    return dict(zip(zip(np.minimum(a, b).tolist(), np.maximum(a, b).tolist()), range(graph.nb_edges())))
+
+
+def _attach(graph, table, name, keys, values, translate, overwrite):
+    names = graph.vertex_properties() if table == 'vertex' else graph.edge_properties()
+    if name in names:
+        if not overwrite:
+            raise ValueError("Existing {} property '{}'".format(table, name))
+        (graph.remove_vertex_property if table == 'vertex' else graph.remove_edge_property)(name)
+    (graph.add_vertex_property if table == 'vertex' else graph.add_edge_property)(name)
+    target = graph.vertex_property(name) if table == 'vertex' else graph.edge_property(name)
+    for k, v in zip(keys, values):
+        target[translate[k]] = v
+    return "Done."
+
+
+def add_vertex_property_from_dictionary(graph, name, dictionary, mlabel2vertex=None, time_point=None, overwrite=False):
+    return _attach(graph, 'vertex', name, dictionary.keys(), dictionary.values(),
+                   label2vertex_map(graph, time_point) if mlabel2vertex is None else mlabel2vertex, overwrite)
+
+
+def add_vertex_property_from_label_and_value(graph, name, labels, property_values, mlabel2vertex=None, overwrite=False):
+    return _attach(graph, 'vertex', name, labels, property_values,
+                   label2vertex_map(graph) if mlabel2vertex is None else mlabel2vertex, overwrite)
+
+
+def add_edge_property_from_dictionary(graph, name, dictionary, mlabelpair2edge=None, time_point=None, overwrite=False):
+    return _attach(graph, 'edge', name, dictionary.keys(), dictionary.values(),
+                   labelpair2edge_map(graph, time_point) if mlabelpair2edge is None else mlabelpair2edge, overwrite)
+
+
+def add_edge_property_from_label_and_value(graph, name, label_pairs, property_values, mlabelpair2edge=None, overwrite=False):
+    return _attach(graph, 'edge', name, label_pairs, property_values,
+                   labelpair2edge_map(graph) if mlabelpair2edge is None else mlabelpair2edge, overwrite)
+
+
+add_vertex_property_from_label_property = add_vertex_property_from_dictionary
+add_edge_property_from_label_property = add_edge_property_from_dictionary
+
+
+def retrieve_label_neighbors(SpI_Analysis, label, labelset, min_contact_area, real_area):
+    return set(SpI_Analysis.neighbors(label, min_contact_area, real_area)) & labelset
+
+
+# ----------------------------------------------------------------------------- DataFrame export
 def property_graph_to_dataframe(graph, element='vertex', labels=None):
-    """tissue_analysis_oalab/property_graph_to_dataframe.py:23-58: scalar properties become columns,
-    'barycenter' becomes barycenter_x/_y/_z; rows are vertex (or edge) ids.  A property that is not
-    defined on every row (e.g. 'epidermis_surface', L1 cells only) gives NaN there; the reference
-    raises KeyError in that case."""
+    """tissue_analysis_oalab/property_graph_to_dataframe.py:23-58 on the tables: every scalar property becomes a column,
+    'barycenter' becomes barycenter_x / _y / _z, rows are the vertex ids (`labels` restricts them) or the ids of the edges
+    between them.  A property not defined on a row gives NaN there (the reference raises KeyError)."""
     import pandas as pd
-    graph_labels = list(graph.vertices())
-    if labels is not None:
-        labels = list(set(graph_labels) & set(list(labels)))
-    else:
-        labels = graph_labels
-    dataframe = pd.DataFrame()
+    vrow = np.arange(graph.nb_vertices()) if labels is None else np.unique(graph.vertex_rows(list(labels)))
+    vrow = vrow[vrow >= 0]
     if element == 'vertex':
-        dataframe['id'] = np.array(list(labels))
-        for name in graph.vertex_property_names():
-            prop = graph.vertex_property(name)
-            if len(prop) == 0:
-                continue
-            if np.array(next(iter(prop.values()))).ndim == 0:
-                dataframe[name] = np.array([prop.get(v, np.nan) for v in labels])
-            elif name == 'barycenter':
-                for i, axis in enumerate(['x', 'y', 'z']):
-                    dataframe[name + "_" + axis] = np.array([prop[v][i] if v in prop else np.nan for v in labels])
+        rows, ids, table = vrow, graph.vertex_ids[vrow], 'vertex'
     elif element == 'edge':
-        labelset = set(labels)
-        graph_edges = [e for e in graph.edges() if all(v in labelset for v in graph.edge_vertices(e))]
-        dataframe['id'] = np.array(list(graph_edges))
-        for name in graph.edge_property_names():
-            prop = graph.edge_property(name)
-            if len(prop) == 0:
+        chosen = np.zeros(graph.nb_vertices(), dtype=bool)
+        chosen[vrow] = True
+        rows = np.flatnonzero(chosen[graph.vertex_rows(graph.edge_sources)] & chosen[graph.vertex_rows(graph.edge_targets)])
+        ids, table = rows, 'edge'
+    else:
+        return pd.DataFrame()
+    data = {}
+    for name in (graph.vertex_property_names() if table == 'vertex' else graph.edge_property_names()):
+        values, valid = graph.vertex_column(name) if table == 'vertex' else graph.edge_column(name)
+        if not valid.any():
+            continue
+        if values.dtype == object:
+            first = np.asarray(values[np.flatnonzero(valid)[0]])
+            if first.ndim or not (np.issubdtype(first.dtype, np.number) or first.dtype == np.bool_):
                 continue
-            if np.array(next(iter(prop.values()))).ndim == 0:
-                dataframe[name] = np.array([prop.get(e, np.nan) for e in graph_edges])
-    dataframe = dataframe.set_index('id')
-    dataframe.index.name = None
-    return dataframe
+            values = np.array([v if ok else np.nan for v, ok in zip(values, valid)])
+        if values.ndim == 1:
+            data[name] = values[rows] if valid[rows].all() else np.where(valid[rows], values[rows].astype(np.float64), np.nan)
+        elif name == 'barycenter':
+            for k, axis in enumerate('xyz'[:values.shape[1]]):
+                data[name + "_" + axis] = np.where(valid[rows], values[rows, k], np.nan)
+    return pd.DataFrame(data, index=ids)
