@@ -12,11 +12,92 @@ scans voxels.  Formulas (SURVEY.md §8 "Semantics"):
 """
 from __future__ import annotations
 
+from collections.abc import Mapping
+
 import numpy as np
 
 from . import _capi
 
 PAIR_ORDER = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
+
+
+def sym3_eig(matrices, sweeps=12):
+    """Eigen-decomposition of MANY symmetric 3x3 matrices at once: cyclic Jacobi, every rotation a handful of array
+    operations over all matrices.  Returns (values [n, 3] unordered, vectors [n, 3, 3] with eigenvectors as COLUMNS).
+    Jacobi rotations are exactly orthogonal transforms, so eigenvalues are good to a few ulps of the matrix norm and the
+    vectors orthonormal to rounding; matrices that are already diagonal are left untouched (identity vectors)."""
+    a = np.array(matrices, dtype=np.float64)
+    n = a.shape[0]
+    d = [a[:, 0, 0].copy(), a[:, 1, 1].copy(), a[:, 2, 2].copy()]
+    off = {(0, 1): a[:, 0, 1].copy(), (0, 2): a[:, 0, 2].copy(), (1, 2): a[:, 1, 2].copy()}
+    v = [[np.ones(n) if r == c else np.zeros(n) for c in range(3)] for r in range(3)]       # v[r][c]
+    scale = np.abs(a).reshape(n, 9).max(axis=1) if n else np.zeros(0)
+    tiny = np.finfo(np.float64).tiny
+    for _ in range(sweeps):
+        if not n or not (np.abs(off[(0, 1)]) + np.abs(off[(0, 2)]) + np.abs(off[(1, 2)]) > 1e-300 + 4e-16 * scale).any():
+            break
+        for p, q in ((0, 1), (0, 2), (1, 2)):
+            r = 3 - p - q
+            apq = off[(p, q)]
+            live = np.abs(apq) > tiny
+            theta = (d[q] - d[p]) / np.where(live, 2.0 * apq, 1.0)
+            t = np.where(theta >= 0.0, 1.0, -1.0) / (np.abs(theta) + np.hypot(theta, 1.0))
+            t = np.where(live, t, 0.0)
+            c = 1.0 / np.sqrt(t * t + 1.0)
+            sn = t * c
+            d[p] = d[p] - t * apq
+            d[q] = d[q] + t * apq
+            off[(p, q)] = np.zeros(n)
+            kp, kq = (min(r, p), max(r, p)), (min(r, q), max(r, q))
+            arp, arq = off[kp], off[kq]
+            off[kp], off[kq] = c * arp - sn * arq, sn * arp + c * arq
+            for row in range(3):
+                vp, vq = v[row][p], v[row][q]
+                v[row][p], v[row][q] = c * vp - sn * vq, sn * vp + c * vq
+    values = np.stack(d, axis=1)
+    vectors = np.stack([np.stack(v[row], axis=1) for row in range(3)], axis=1)
+    return values, vectors
+
+
+class NeighborRows(Mapping):
+    """label -> ascending list of its face neighbours, as a read-only mapping over the CSR rows of the adjacency.  Nothing is
+    built until it is used: `indptr` / `indices` are the arrays (made on first access), the lists are made per lookup;
+    `keys_array` holds the labels it answers for."""
+
+    def __init__(self, keys, extraction):
+        self.keys_array = np.asarray(keys, dtype=np.int64)
+        self._x = extraction
+        self._known = None
+
+    @property
+    def indptr(self):
+        return self._x._adjacency_csr()[0]
+
+    @property
+    def indices(self):
+        return self._x._adjacency_csr()[1]
+
+    def _has(self, label):
+        if self._known is None:
+            self._known = set(self.keys_array.tolist())
+        return label in self._known
+
+    def __getitem__(self, label):
+        if not self._has(label):
+            raise KeyError(label)
+        ptr = self.indptr
+        if 0 <= label < ptr.size - 1:
+            return self.indices[ptr[label]:ptr[label + 1]].tolist()
+        return []
+
+    def __contains__(self, label):
+        return self._has(label)
+
+    def __iter__(self):
+        return iter(self.keys_array.tolist())
+
+    def __len__(self):
+        return int(self.keys_array.size)
 
 
 class Extraction(object):
@@ -35,6 +116,7 @@ class Extraction(object):
         self.pair_faces = np.asarray(pair_faces, dtype=np.uint64).reshape(-1, 3)
         self.timing = timing
         self._csr = None
+        self._derived = {}
 
     @classmethod
     def from_arrays(cls, shape, arrays, timing=None):
@@ -47,10 +129,42 @@ class Extraction(object):
                     sum2=self.sum2, pair_lo=self.pair_lo, pair_hi=self.pair_hi,
                     pair_faces=self.pair_faces)
 
+    def _cached(self, name, make):
+        if name not in self._derived:
+            self._derived[name] = make()
+        return self._derived[name]
+
     # ------------------------------------------------------------------ labels / boxes
     def present(self):
         """Ascending ids of the labels that own at least one voxel."""
-        return np.nonzero(self.count)[0]
+        return self._cached("present", lambda: np.nonzero(self.count)[0])
+
+    @property
+    def lo(self):
+        """The pair list as int64 index arrays / float64 face counts, converted once."""
+        return self._cached("lo", lambda: self.pair_lo.astype(np.int64))
+
+    @property
+    def hi(self):
+        return self._cached("hi", lambda: self.pair_hi.astype(np.int64))
+
+    @property
+    def faces(self):
+        return self._cached("faces", lambda: self.pair_faces.astype(np.float64))
+
+    def pair_areas(self, face_surface=None):
+        """float64 [P]: F0 s0 + F1 s1 + F2 s2 of every pair (SIA:751-756, 953), or F0 + F1 + F2 without face areas.  One
+        expression for every caller, so that a threshold on an area decides the same way everywhere."""
+        f = self.faces
+        if face_surface is None:
+            return self._cached("area_voxels", lambda: f[:, 0] + f[:, 1] + f[:, 2])
+        s = tuple(float(v) for v in face_surface)
+        return self._cached(("area", s), lambda: f[:, 0] * s[0] + f[:, 1] * s[1] + f[:, 2] * s[2])
+
+    def degrees(self):
+        """int64 [max_label + 2]: how many labels share a face with each label."""
+        return self._cached("degree", lambda: np.bincount(self.lo, minlength=self.max_label + 2)
+                            + np.bincount(self.hi, minlength=self.max_label + 2))
 
     def has(self, label):
         return 0 <= label <= self.max_label and self.count[label] > 0
@@ -69,10 +183,14 @@ class Extraction(object):
         have = (self.count[1:top + 1] > 0).tolist()
         return [(slice(b[0], b[3]), slice(b[1], b[4]), slice(b[2], b[5])) if h else None for b, h in zip(rows, have)]
 
+    def neighbor_rows(self, labels):
+        """The same answer as `neighbor_lists` without making the lists: a mapping view over the CSR arrays."""
+        return NeighborRows(labels, self)
+
     def neighbor_lists(self, labels):
         """{label: ascending list of its face neighbours} for many labels at once."""
         ptr, dst, _ = self._adjacency_csr()
-        flat, p = dst.tolist(), ptr.tolist()
+        flat, p = self._cached("csr_lists", lambda: (dst.tolist(), ptr.tolist()))
         n = len(p) - 1
         return dict((l, flat[p[l]:p[l + 1]] if 0 <= l < n else []) for l in labels)
 
@@ -107,16 +225,15 @@ class Extraction(object):
         return cov
 
     def inertia(self, labels):
-        """(vectors [n,3,3] rows = axes, values [n,3]) sorted by decreasing eigenvalue, like
-        eigen_values_vectors (SIA:152-167) which calls np.linalg.eig and re-orders."""
+        """(vectors [n,3,3] rows = axes, values [n,3]) sorted by decreasing eigenvalue, like eigen_values_vectors
+        (SIA:152-167).  The reference calls np.linalg.eig per label (LAPACK geev, one Python call each); here all the
+        symmetric 3x3 covariances are diagonalised together by cyclic Jacobi rotations (`sym3_eig`): eigenvalues to
+        ~1e-16 of the matrix norm, eigenvectors up to sign -- like any eigen-solver."""
         cov = self.covariances(labels)
         if cov.shape[0] == 0:
             return np.zeros((0, 3, 3)), np.zeros((0, 3))
-        cov = np.where(np.isfinite(cov), cov, 0.0)
-        val, vec = np.linalg.eig(cov)                    # LAPACK geev per matrix, same call as SIA:163
-        val = np.real(val)
-        vec = np.real(vec)
-        order = np.argsort(val, axis=1)[:, ::-1]
+        val, vec = sym3_eig(np.where(np.isfinite(cov), cov, 0.0))
+        order = np.argsort(-val, axis=1, kind="stable")
         val = np.take_along_axis(val, order, axis=1)
         vec = np.take_along_axis(vec, order[:, None, :], axis=2)      # columns re-ordered
         return np.transpose(vec, (0, 2, 1)), val                      # rows = eigenvectors
@@ -124,17 +241,15 @@ class Extraction(object):
     # ------------------------------------------------------------------ adjacency
     def _adjacency_csr(self):
         if self._csr is None:
-            lo = self.pair_lo.astype(np.int64)
-            hi = self.pair_hi.astype(np.int64)
+            lo, hi = self.lo, self.hi
             src = np.concatenate([lo, hi])
             dst = np.concatenate([hi, lo])
             pid = np.concatenate([np.arange(lo.size), np.arange(lo.size)])
-            order = np.lexsort((dst, src))
-            src, dst, pid = src[order], dst[order], pid[order]
             nrows = max(self.max_label + 1, int(src.max()) + 1 if src.size else 0)
+            order = np.argsort(src * np.int64(nrows) + dst, kind="stable")
             ptr = np.zeros(nrows + 1, dtype=np.int64)
-            np.add.at(ptr, src + 1, 1)
-            self._csr = (np.cumsum(ptr), dst, pid)
+            np.cumsum(np.bincount(src, minlength=nrows), out=ptr[1:])
+            self._csr = (ptr, dst[order], pid[order])
         return self._csr
 
     def neighbors_of(self, label):
@@ -147,9 +262,12 @@ class Extraction(object):
     def surface_faces(self, labels):
         """uint64 [n, 3]: per-axis number of voxel faces each label shares with ANY other label (faces on the border
         of the volume belong to no wall and are not counted): the row sums of the adjacency."""
-        out = np.zeros((self.max_label + 2, 3), dtype=np.uint64)
-        np.add.at(out, self.pair_lo.astype(np.int64), self.pair_faces)
-        np.add.at(out, self.pair_hi.astype(np.int64), self.pair_faces)
+        def rows():
+            n = self.max_label + 2
+            return np.stack([(np.bincount(self.lo, weights=self.faces[:, d], minlength=n)
+                              + np.bincount(self.hi, weights=self.faces[:, d], minlength=n)) for d in range(3)],
+                            axis=1).astype(np.uint64)            # (float64 sums of integers far below 2^53: exact)
+        out = self._cached("surface_faces", rows)
         idx = np.asarray(labels, dtype=np.int64)
         idx = np.where((idx >= 0) & (idx <= self.max_label), idx, self.max_label + 1)     # unknown labels: the zero row
         return out[idx]

@@ -14,7 +14,13 @@ Documented divergences (DESIGN.md "Reference quirks"):
 * 2D images are handled by this same class as (X, Y, 1) volumes (the reference's
   ``SpatialImageAnalysis2D`` does not exist, SIA:1677);
 * the image is uploaded and swept at construction; mutating ``self.image`` afterwards needs
-  ``refresh()``.
+  ``refresh()``;
+* ``return_type=NPLIST`` is the ARRAY mode: where the reference hands back "the values as they are" (SIA:309-334) the
+  values here are numpy arrays over the requested labels, with no per-label Python objects -- ``volume`` [n],
+  ``center_of_mass`` [n, 3], ``boundingbox`` [n, 6] (starts, then stops), ``neighbors_number`` [n], ``surface_area`` [n],
+  ``inertia_axis`` ([n, 3, 3], [n, 3]), ``wall_areas()`` (pairs [m, 2], areas [m]); ``neighbors()`` is a read-only mapping
+  over the adjacency's CSR arrays (`.indptr`, `.indices`) whose lists are made when a label is looked up.  (The reference returns dicts from
+  ``center_of_mass`` / ``neighbors_number`` / ``wall_areas`` whatever the return type; DICT and LIST do exactly that.)
 There is no CPU fallback: constructing an analysis without the built HIP library or without a GPU
 raises.
 """
@@ -178,7 +184,21 @@ class AbstractSpatialImageAnalysis(object):
         return self._labels
 
     def __labels(self):
-        return [int(l) for l in self._x.present() if int(l) not in self._ignoredlabels]
+        return self._label_array().tolist()
+
+    def _label_array(self):
+        """The labels of the image that are not ignored, ascending (int64)."""
+        present = self._x.present()
+        if not self._ignoredlabels:
+            return present
+        ignored = np.fromiter(self._ignoredlabels, dtype=np.int64, count=len(self._ignoredlabels))
+        return present[~np.isin(present, ignored)]
+
+    def _request_array(self, labels):
+        """`label_request` as an int64 array (what the array paths index the accumulators with)."""
+        if labels is None:
+            return np.asarray(self.labels(), dtype=np.int64)
+        return np.asarray(self.label_request(labels), dtype=np.int64)
 
     def nb_labels(self):
         return len(self.labels())
@@ -211,17 +231,17 @@ class AbstractSpatialImageAnalysis(object):
     # -- barycentre (SIA:417-480): sum1 / count from the sweep
     def center_of_mass(self, labels=None, real=True, verbose=False):
         labels = self.label_request(labels)
-        todo = [l for l in labels if l not in self._center_of_mass]
-        if todo:
-            com = self._x.barycenters(todo)
-            for l, c in zip(todo, com):
-                self._center_of_mass[l] = c
-        center = dict((l, self._center_of_mass[l]) for l in labels)
+        idx = np.asarray(labels, dtype=np.int64)
+        com = self._x.barycenters(np.where((idx >= 0) & (idx <= self._x.max_label), idx, 0)) if idx.size else np.zeros((0, 3))
+        if len(self._center_of_mass) < len(labels):                  # the reference's cache, voxel units (SIA:471)
+            self._center_of_mass.update(zip(labels, com))
         if real:
-            center = dict((l, np.multiply(center[l], self._voxelsize)) for l in labels)
+            com = com * np.asarray(self._voxelsize, dtype=np.float64)
         if len(labels) == 1:
-            return center[labels[0]]
-        return center
+            return com[0]
+        if self.return_type == NPLIST:
+            return com
+        return dict(zip(labels, com))
 
     # -- bounding boxes (SIA:483-535): min/max from the sweep, list indexed by label - 1
     def _bbox_list(self):
@@ -237,11 +257,17 @@ class AbstractSpatialImageAnalysis(object):
             if zero is None:
                 raise IndexError("list index out of range")   # nd.find_objects(image == 0)[0]
             return zero
-        boxes = self._bbox_list()
         if labels is None:
             labels = copy.copy(self.labels())
             if self.background() is not None:
                 labels.append(self.background())
+        if isinstance(labels, list) and self.return_type == NPLIST:
+            idx = np.asarray(labels, dtype=np.int64)
+            if idx.size and (idx.min() < 1 or idx.max() > self._x.max_label):
+                raise IndexError("list index out of range")
+            box = self._x.bbox[idx]
+            return box * np.tile(np.asarray(self._voxelsize, dtype=np.float64), 2) if real else box
+        boxes = self._bbox_list()
         if isinstance(labels, list):
             found = [boxes[i - 1] for i in labels]
             if real:
@@ -278,17 +304,20 @@ class AbstractSpatialImageAnalysis(object):
 
     def _all_neighbors(self, min_contact_area=None, real_area=True):
         if self._neighbors is None:
-            boxes = self.boundingbox()
+            keys = copy.copy(self.labels())                              # the keys of boundingbox() (SIA:639)
+            if self.background() is not None:
+                keys.append(self.background())
             if self.return_type in (NPLIST, LIST):
-                boxes = dict((i + 1, b) for i, b in enumerate(boxes))   # SIA:642-645, as written
-            self._neighbors = self._x.neighbor_lists([int(l) for l in boxes])
+                keys = list(range(1, len(keys) + 1))                     # SIA:642-645, as written: re-keyed by position
+            # (NPLIST: a mapping view over the adjacency's CSR arrays -- the lists are made when a label is looked up)
+            self._neighbors = self._x.neighbor_rows(keys) if self.return_type == NPLIST else self._x.neighbor_lists(keys)
         if min_contact_area is None:
             return self._neighbors
         return self._filter_with_area(self._neighbors, min_contact_area, real_area)
 
     def _filter_with_area(self, neighborhood_dictionary, min_contact_area, real_area):
-        return dict((l, self._neighbors_filtering_by_contact_area(l, n, min_contact_area, real_area))
-                    for l, n in neighborhood_dictionary.items())
+        return dict((l, self._neighbors_filtering_by_contact_area(l, neighborhood_dictionary[l], min_contact_area, real_area))
+                    for l in neighborhood_dictionary)
 
     def _neighbors_filtering_by_contact_area(self, label, neighbors, min_contact_area, real_area):
         areas = self.cell_wall_area(label, list(neighbors), real_area)
@@ -316,6 +345,10 @@ class AbstractSpatialImageAnalysis(object):
         return self._kernels
 
     def neighbors_number(self, labels=None, min_contact_area=None, real_area=True, verbose=True):
+        if self.return_type == NPLIST and min_contact_area is None and (labels is None or isinstance(labels, list)):
+            idx = self._request_array(labels) if labels is not None else np.asarray(list(self._all_neighbors()), dtype=np.int64)
+            degree = self._x.degrees()
+            return degree[np.where((idx >= 0) & (idx < degree.size), idx, degree.size - 1)]
         nei = self.neighbors(labels, min_contact_area, real_area, verbose)
         if isinstance(nei, dict):
             return dict((k, len(v)) for k, v in nei.items())
@@ -332,9 +365,10 @@ class AbstractSpatialImageAnalysis(object):
             neighbors = [neighbors]
         faces = self._x.faces_between(int(label_id), [int(n) for n in neighbors]).astype(np.float64)
         if real:
-            area = faces.dot(self.get_voxel_face_surface().astype(np.float64))
+            surf = self.get_voxel_face_surface()
+            area = faces[:, 0] * float(surf[0]) + faces[:, 1] * float(surf[1]) + faces[:, 2] * float(surf[2])
         else:
-            area = faces.sum(axis=1)
+            area = faces[:, 0] + faces[:, 1] + faces[:, 2]
         wall = {}
         for n, a in zip(neighbors, area):
             key = (min(label_id, n), max(label_id, n))
@@ -347,12 +381,16 @@ class AbstractSpatialImageAnalysis(object):
         if neighbors is None:
             # every wall of every label: one pass over the sweep's pair list instead of one cell_wall_area call per label
             # (same dictionary: the walls (l, n), n > l, of the labels l that neighbors() has as keys)
-            keys = np.fromiter(self.neighbors().keys(), dtype=np.int64)
             x = self._x
-            sel = np.isin(x.pair_lo.astype(np.int64), keys)
-            faces = x.pair_faces[sel].astype(np.float64)
-            area = faces.dot(self.get_voxel_face_surface().astype(np.float64)) if real else faces.sum(axis=1)
-            return dict(zip(zip(x.pair_lo[sel].tolist(), x.pair_hi[sel].tolist()), area.tolist()))
+            nei = self.neighbors()
+            keys = np.fromiter(nei.keys(), dtype=np.int64, count=len(nei))
+            is_key = np.zeros(max(x.max_label + 2, int(keys.max()) + 1 if keys.size else 0), dtype=bool)
+            is_key[keys] = True
+            sel = np.flatnonzero(is_key[x.lo])
+            area = x.pair_areas(self.get_voxel_face_surface() if real else None)[sel]
+            if self.return_type == NPLIST:
+                return np.stack([x.lo[sel], x.hi[sel]], axis=1), area
+            return dict(zip(zip(x.lo[sel].tolist(), x.hi[sel].tolist()), area.tolist()))
         areas = {}
         for label_id, lneighbors in neighbors.items():
             neigh = [n for n in lneighbors if n > label_id]
@@ -369,9 +407,10 @@ class AbstractSpatialImageAnalysis(object):
         req = [int(labels)] if single else self.label_request(labels)
         faces = self._x.surface_faces(req).astype(np.float64)
         if real:
-            area = faces @ np.asarray(self.get_voxel_face_surface(), dtype=np.float64)
+            surf = self.get_voxel_face_surface()
+            area = faces[:, 0] * float(surf[0]) + faces[:, 1] * float(surf[1]) + faces[:, 2] * float(surf[2])
         else:
-            area = faces.sum(axis=1)
+            area = faces[:, 0] + faces[:, 1] + faces[:, 2]
         return float(area[0]) if single else self.convert_return(area, req)
 
     # -- layers and margins (SIA:996-1022): host post-processing of the sweep results
@@ -586,12 +625,13 @@ class SpatialImageAnalysis3D(AbstractSpatialImageAnalysis):
         vecs, vals = self._x.inertia(labels)
         if real:
             vals = vals * np.linalg.norm(vecs * np.asarray(self._voxelsize, dtype=np.float64), axis=2)
-        inertia_eig_vec = [v for v in vecs]
-        inertia_eig_val = [v for v in vals]
         if len(labels) == 1:
-            return return_list_of_vectors(inertia_eig_vec[0]), inertia_eig_val[0]
-        return (self.convert_return(return_list_of_vectors(inertia_eig_vec), labels),
-                self.convert_return(inertia_eig_val, labels))
+            return return_list_of_vectors(vecs[0]), vals[0]
+        if self.return_type == NPLIST:
+            return vecs, vals                                           # [n, 3, 3] (rows = axes), [n, 3]
+        rows = list(vecs.reshape(-1, 3))                                # return_list_of_vectors for all labels at once
+        axes = [rows[k:k + 3] for k in range(0, len(rows), 3)]
+        return self.convert_return(axes, labels), self.convert_return(list(vals), labels)
 
     def reduced_inertia_axis(self, labels=None, real=True, verbose=False):  # SIA:1295-1341
         return self.inertia_axis(labels, real, verbose)
@@ -604,12 +644,13 @@ class SpatialImageAnalysis3D(AbstractSpatialImageAnalysis):
         present = x.present()
         if present.size == 0:
             return []
-        if d <= 0:   # image[-0:] is the whole image in the reference's slicing
-            return [int(l) for l in present if int(l) != self._background]
-        box = x.bbox[present]
-        shape = np.asarray(x.shape, dtype=np.int64)
-        near = (box[:, :3] < d).any(axis=1) | (box[:, 3:] > shape - d).any(axis=1)
-        return [int(l) for l in present[near] if int(l) != self._background]
+        if d > 0:    # (image[-0:] is the whole image in the reference's slicing: distance 0 names every label)
+            box = x.bbox[present]
+            shape = np.asarray(x.shape, dtype=np.int64)
+            present = present[(box[:, :3] < d).any(axis=1) | (box[:, 3:] > shape - d).any(axis=1)]
+        if self._background is not None:
+            present = present[present != self._background]
+        return present.tolist()
 
     def region_boundingbox(self, labels):  # SIA:1361-1396
         if isinstance(labels, list) and len(labels) == 1:
