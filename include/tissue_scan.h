@@ -31,7 +31,10 @@
 extern "C" {
 #endif
 
-#define TA_ABI_VERSION 1
+/* 2: ta_wall_voxels_get takes (pairs, coords, ms); ta_ctx_set_stream(NULL) = the device's legacy default stream;
+ *    TA_OPT_IMPL is 0 or 1; ta_adjacency_scope added; ta_timing answers zeros when no events were recorded.
+ * A caller checks ta_version() == TA_ABI_VERSION of the header it was built against (the ctypes binding does). */
+#define TA_ABI_VERSION 2
 
 #if defined(TA_BUILD)
 #define TA_API __attribute__((visibility("default")))
@@ -67,7 +70,7 @@ extern "C" {
                                * 2 = also the step's begin / end (two event records, ~4 us of queue time each)      */
 #define TA_OPT_VOLUME_SLACK 6 /* bytes that are readable behind the volume adopted by ta_volume_set_device (reset to 0 by that
                                * call): with >= 16 the sweep uses 16-byte loads whatever the row length -- the strip that
-                               * straddles the end of the last row reads up to 12 bytes past the volume                   */
+                               * straddles the end of the last row reads up to 16 - itemsize bytes past the volume        */
 #define TA_OPT_TIMING_RING 5  /* sweep durations kept for ta_timing_series: the last N extractions, N in [1,4096]
                                * (default 1); setting it drains the stream and starts a new series             */
 
@@ -128,7 +131,7 @@ TA_API int ta_get_labels(ta_ctx* ctx, uint64_t* count, int32_t* bbox, uint64_t* 
 TA_API int ta_adjacency_size(ta_ctx* ctx, int64_t* npairs);
 TA_API int ta_adjacency_get(ta_ctx* ctx, uint32_t* lo, uint32_t* hi, uint64_t* faces);
 
-/* Timing of the last ta_extract (HIP events on the context stream): the sweep kernel alone; with TA_OPT_TIMING = 2
+/* Timing of the last ta_extract (HIP events on the context stream; zeros when TA_OPT_TIMING is 0): the sweep kernel alone; with TA_OPT_TIMING = 2
  * also what follows it (fold of the per-workgroup hot-label rows + adjacency collection) and the whole call from
  * the accumulator init on (0 otherwise); bytes_read = nvox * itemsize (algorithmic bytes).
  * ta_timing_series: the sweep kernel's duration of each of the last extractions (oldest first, at most capacity and
@@ -173,6 +176,16 @@ TA_API int ta_adjacency_export(ta_ctx* ctx, void* keys_dst_dev, void* faces_dst_
 /* Merge foreign pair lists (other ranks' ta_adjacency_device output, gathered by the host with
  * RCCL) into this context's adjacency: sums face counts of equal keys. */
 TA_API int ta_adjacency_merge(ta_ctx* ctx, const void* keys_dev, const void* faces_dev, int64_t npairs);
+
+/* Which pairs the adjacency getters (ta_adjacency_size / _get / _device / _export) answer with right now:
+ *   TA_ADJ_LOCAL    every pair of this context's own volume (after ta_extract);
+ *   TA_ADJ_MERGED   the pairs of ALL ranks' blocks (after ta_adjacency_pack on every rank + ta_adjacency_merge_blocks);
+ *   TA_ADJ_PARTIAL  this rank's PRIVATE pairs plus all ranks' travelling pairs (after ta_adjacency_pack_shared +
+ *                   ta_adjacency_merge_blocks): NOT the list of any volume -- the global list is the union over ranks. */
+#define TA_ADJ_LOCAL   0
+#define TA_ADJ_MERGED  1
+#define TA_ADJ_PARTIAL 2
+TA_API int ta_adjacency_scope(ta_ctx* ctx, int* scope);
 
 /* ---- label lookup-table sweeps over the resident volume -------------------
  * ta_volume_relabel: in place, v -> lut[v] for v < lut_len, other voxels unchanged.  Replaces the

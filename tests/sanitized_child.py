@@ -18,7 +18,7 @@ from oracle import onepass, onepass_c          # noqa: E402  (the checker: this 
 def walk_c_abi():
     lib = _capi.load()
     assert os.path.samefile(_capi.LIB_PATH, os.environ["TISSUE_SCAN_LIB"])
-    assert lib.ta_version() == 1
+    assert lib.ta_version() == 2
     n = ctypes.c_int(-1)
     assert lib.ta_device_count(ctypes.byref(n)) in (_capi.TA_OK, _capi.TA_ENODEVICE)
     assert lib.ta_device_count(None) == _capi.TA_EINVAL
@@ -64,6 +64,7 @@ def walk_c_abi():
         "ta_accumulators_device": (None, ctypes.byref(vp), ctypes.byref(vp), ctypes.byref(u32)),
         "ta_accumulators_reduced": (None,),
         "ta_adjacency_device": (None, ctypes.byref(vp), ctypes.byref(vp), ctypes.byref(i64)),
+        "ta_adjacency_scope": (None, ctypes.byref(ctypes.c_int(0))),
         "ta_adjacency_export": (None, buf, buf, 4),
         "ta_adjacency_merge": (None, buf, buf, 4),
         "ta_adjacency_pack": (None, buf, 4),

@@ -63,8 +63,13 @@ def test_two_slabs_exchange_blocks_by_hand(shared):
             assert sent == npairs
         lists = []
         for ctx, _, _ in jobs:
+            assert ctx.adjacency_scope() == _capi.ADJ_LOCAL
             ctx.adjacency_merge_blocks(blocks.data_ptr(), 2, cap)
-            lists.append(ctx.adjacency())
+            assert ctx.adjacency_scope() == (_capi.ADJ_PARTIAL if shared else _capi.ADJ_MERGED)
+            if shared:                     # a partial list is handed out only when asked for by name
+                with pytest.raises(_capi.TissueScanError):
+                    ctx.adjacency()
+            lists.append(ctx.adjacency(allow_partial=True))
         if not shared:                     # every rank holds the global list
             for lo, hi, faces in lists:
                 assert np.array_equal(lo, want["pair_lo"]) and np.array_equal(hi, want["pair_hi"]) and np.array_equal(faces, want["pair_faces"])

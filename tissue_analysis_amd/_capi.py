@@ -16,6 +16,8 @@ LIB_PATH = os.environ.get("TISSUE_SCAN_LIB") or os.path.join(_HERE, "libtissue_s
 TA_OK, TA_EINVAL, TA_EHIP, TA_ENOMEM, TA_ERANGE, TA_ECAPACITY, TA_ENODEVICE = 0, -1, -2, -3, -4, -5, -6
 F_VOLUME, F_BBOX, F_MOMENT1, F_MOMENT2, F_ADJACENCY = 1, 2, 4, 8, 16
 F_ALL = 31
+ADJ_LOCAL, ADJ_MERGED, ADJ_PARTIAL = 0, 1, 2
+ABI_VERSION = 2          # TA_ABI_VERSION of include/tissue_scan.h this binding was written against
 FEATURES = dict(VOLUME=F_VOLUME, BBOX=F_BBOX, MOMENT1=F_MOMENT1, MOMENT2=F_MOMENT2,
                 ADJACENCY=F_ADJACENCY)
 OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS, OPT_TIMING, OPT_TIMING_RING, OPT_VOLUME_SLACK = 1, 2, 3, 4, 5, 6
@@ -23,7 +25,7 @@ STREAM_LEGACY_DEFAULT = 1          # TA_STREAM_LEGACY_DEFAULT of include/tissue_
 
 # every symbol include/tissue_scan.h declares
 SYMBOLS = (
-    "ta_version", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
+    "ta_version", "ta_adjacency_scope", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_get_option", "ta_ctx_synchronize", "ta_volume_set",
     "ta_volume_set_device", "ta_volume_max_label", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
     "ta_volume_first_layer", "ta_wall_voxels_count", "ta_wall_voxels_get", "ta_wall_voxels_get_by_pair",
@@ -72,6 +74,7 @@ def load():
     P = ctypes.POINTER
     sig = {
         "ta_version": (ci, []),
+        "ta_adjacency_scope": (ci, [vp, P(ci)]),
         "ta_last_error": (ctypes.c_char_p, []),
         "ta_device_count": (ci, [P(ci)]),
         "ta_ctx_create": (ci, [ci, P(vp)]),
@@ -116,6 +119,9 @@ def load():
     for name in SYMBOLS:
         fn = getattr(lib, name)      # AttributeError here == the .so does not match the header
         fn.restype, fn.argtypes = sig[name]
+    if lib.ta_version() != ABI_VERSION:
+        raise ImportError("%s speaks ABI version %d, this binding %d: rebuild it (python -m tissue_analysis_amd.build --force)"
+                          % (LIB_PATH, lib.ta_version(), ABI_VERSION))
     _lib = lib
     return lib
 
@@ -312,8 +318,19 @@ class Context(object):
         _check(self._lib.ta_adjacency_size(self._h, ctypes.byref(n)))
         return int(n.value)
 
-    def adjacency(self):
-        """(lo u32[n], hi u32[n], faces u64[n,3]) sorted by (lo, hi)."""
+    def adjacency_scope(self):
+        """ADJ_LOCAL / ADJ_MERGED / ADJ_PARTIAL: which pairs the adjacency getters answer with right now."""
+        scope = ctypes.c_int(0)
+        _check(self._lib.ta_adjacency_scope(self._h, ctypes.byref(scope)))
+        return scope.value
+
+    def adjacency(self, allow_partial=False):
+        """(lo u32[n], hi u32[n], faces u64[n,3]) sorted by (lo, hi).  After a pack_shared exchange the context holds
+        only this rank's private pairs + the travelling pairs of all ranks: that list is handed out only when asked for
+        by name (SlabJob.result_arrays assembles the global list from it)."""
+        if not allow_partial and self.adjacency_scope() == ADJ_PARTIAL:
+            raise TissueScanError(TA_EINVAL, "this context holds a PARTIAL pair list (private + travelling pairs of a "
+                                             "slab exchange): use SlabJob.result_arrays() for the global list")
         n = ctypes.c_int64(0)
         _check(self._lib.ta_adjacency_size(self._h, ctypes.byref(n)))
         lo = np.zeros(n.value, dtype=np.uint32)

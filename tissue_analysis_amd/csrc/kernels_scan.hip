@@ -50,6 +50,12 @@ namespace ta {
 #ifndef TA_RDRAIN
 #define TA_RDRAIN 120
 #endif
+// 1 = records are stored WITHOUT touching the exec mask: every lane stores at every compare, a lane whose compare did not
+// fire stores into a trash slot behind the wave's buffer (one v_cndmask on the address instead of s_and_saveexec / s_or /
+// s_cbranch_execz around each store: the sweep issues almost as many scalar as vector instructions)
+#ifndef TA_BRANCHLESS
+#define TA_BRANCHLESS 0
+#endif
 constexpr int FCAP = TA_FCAP, RCAP = TA_RCAP;           // record capacities of a wave's buffers
 constexpr int FDRAIN = TA_FDRAIN, RDRAIN = TA_RDRAIN;   // drain a buffer before a row once it holds this much
 constexpr uint32_t ROWID_MASK = 0xFFFFFC00u;            // bits of a run code that name the row (b, a, and the zero top bits)
@@ -59,8 +65,8 @@ typedef __attribute__((address_space(3))) uint32_t* lds_u32;
 
 template <bool ADJ>
 struct __attribute__((aligned(16))) ScanWaveLds {
-    uint2 frec[ADJ ? FCAP : 1];                         // faces of axis 0/1: voxel, neighbour | axis << 30
-    uint32_t cqv[RCAP + 1], cql[RCAP + 1], cqc[RCAP + 1];   // runs; record i lives in slot i + 1, slot 0 = sentinel / carry
+    uint2 frec[ADJ ? FCAP + 1 : 1];                     // faces of axis 0/1: voxel, neighbour | axis << 30; [FCAP] = trash slot
+    uint32_t cqv[RCAP + 2], cql[RCAP + 2], cqc[RCAP + 2];   // runs; record i lives in slot i + 1, slot 0 = sentinel / carry, slot RCAP + 1 = trash
 };
 
 template <int NW, bool ADJ>
@@ -554,11 +560,16 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     };
 
     uint32_t fcount = 0u, rcount = 0u;                    // records in the buffers (wave-uniform)
+#ifdef TA_STAMPS
+    uint64_t tk_cmp = 0, tk_emit = 0, tk_drain = 0, tk_adv = 0, tk_land = 0, tk_evrows = 0, tk_drains = 0;
+#endif
     if (lane == 0) W.cqc[0] = NO_ROW;
     // LDS byte offsets of the wave's buffers (the low half of a flat LDS address is the LDS offset)
     const uint32_t fbase = (uint32_t)(uintptr_t)&W.frec[0];
     const uint32_t rbase = (uint32_t)(uintptr_t)&W.cqv[1];
-    constexpr uint32_t RSTRIDE = (RCAP + 1) * 4u;         // bytes between the three run arrays
+    constexpr uint32_t RSTRIDE = (RCAP + 2) * 4u;         // bytes between the three run arrays
+    const uint32_t ftrash = fbase + (uint32_t)FCAP * 8u;  // where the stores of compares that did not fire go (TA_BRANCHLESS)
+    const uint32_t rtrash = rbase + (uint32_t)RCAP * 4u;
 
     // One packed add-scan over the lanes gives every lane the offset of its first record (faces in the low half of
     // `cnt`, runs in the high half); the totals say whether the records fit.  One trip, unless they do not: then the
@@ -585,13 +596,26 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                 hi = lo + ((hi - lo) >> 1);               // too big even for empty buffers: half the lanes
                 continue;
             }
-            if (!fits || fcount >= (uint32_t)FDRAIN || rcount >= (uint32_t)RDRAIN)
+            if (!fits || fcount >= (uint32_t)FDRAIN || rcount >= (uint32_t)RDRAIN) {
+#ifdef TA_STAMPS
+                const uint64_t td0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef TA_RECCOUNT
+                if (lane == 0) { atomicAdd(&cold_args(kp)->flags[8], fcount); atomicAdd(&cold_args(kp)->flags[9], rcount); atomicAdd(&cold_args(kp)->flags[10], 1u); }
+#endif
                 drain_buffers<ADJ, MOM2, LDS>(kp, S, EDGE, w, lane, fcount, rcount);
+#ifdef TA_STAMPS
+                tk_drain += __builtin_amdgcn_s_memtime() - td0; tk_drains += 1;
+#endif
+            }
             if (lo >= 64u) break;
         }
     };
     // A new plane `nw` has landed: its faces with the current plane (axis 0), while both are in registers.
     auto plane_faces = [&](const uint32_t (&nw)[RB][VPL]) {
+#ifdef TA_ABL_NOFACE0
+        return;                                           // (ablation: results wrong by construction)
+#endif
         uint32_t cf = 0u;
 #pragma unroll
         for (int r = 0; r < RB; ++r)
@@ -605,10 +629,17 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                 for (int j = 0; j < VPL; ++j) {
                     uint32_t v = nw[r][j];
                     asm volatile("" : "+v"(v));           // (compare again: see the row emission)
+#if TA_BRANCHLESS
+                    const bool f = v != cur[r][j];
+                    const uint32_t at = f ? offf : ftrash;
+                    *(lds_u32)(uintptr_t)at = v; *(lds_u32)(uintptr_t)(at + 4u) = cur[r][j];
+                    offf += f ? 8u : 0u;
+#else
                     if (v != cur[r][j]) {
                         *(lds_u32)(uintptr_t)offf = v; *(lds_u32)(uintptr_t)(offf + 4u) = cur[r][j];
                         offf += 8u;
                     }
+#endif
                 }
         });
     };
@@ -643,7 +674,6 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     uint32_t nlead = 0u;
 
 #ifdef TA_STAMPS
-    uint64_t tk_cmp = 0, tk_emit = 0, tk_drain = 0, tk_adv = 0, tk_rows = 0, tk_evrows = 0, tk_drains = 0;
     const uint64_t tk_begin = __builtin_amdgcn_s_memtime();
 #define TA_T() __builtin_amdgcn_s_memtime()
 #endif
@@ -665,6 +695,9 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             if (p + 1 < p_hi) { load_rows(p + 1, nxt); load_halo(p + 1, nxt_up, nxt_leftv); }
         } else {
             Pin<PINB ? PINB : TA_PIN_ADJ>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+#ifdef TA_STAMPS
+            tk_land += TA_T() - t4;
+#endif
             if (p + 1 < p_hi) issue_plane();
             uint32_t nw[RB][VPL], nup[VPL];
 #pragma unroll
@@ -707,6 +740,9 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                 inner |= j == 0 ? (mc & ~1ull) : mc;
                 if (ADJ && (r > 0 || !EDGE || has_up)) cf += (v != (r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j])) ? 1u : 0u;
             }
+#ifdef TA_ABL_NOFACE1
+            cf = 0u;                                      // (ablation: results wrong by construction)
+#endif
             const uint32_t rowlab = __builtin_amdgcn_readfirstlane(cur[r][0]);
             const bool uniform = inner == 0ull;
             bool need_end;                                // the row's last run closes by a record of lane 63
@@ -718,7 +754,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #ifdef TA_STAMPS
             const bool anyev_ = __builtin_amdgcn_ballot_w64(cnt != 0u) != 0ull;
             const uint64_t t1 = TA_T();
-            tk_cmp += t1 - t0; tk_rows += 1;
+            tk_cmp += t1 - t0;
             if (!anyev_) continue;
             tk_evrows += 1;
 #else
@@ -737,6 +773,28 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                     //  alive from the counting pass across the scan -- and across a drain -- in scarce SGPRs)
                     uint32_t v = cur[r][j];
                     asm volatile("" : "+v"(v));
+#if TA_BRANCHLESS
+#ifndef TA_ABL_NOFACE1
+                    if (ADJ && (r > 0 || !EDGE || has_up))
+#else
+                    if (false)
+#endif
+                    {
+                        const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];
+                        const bool f = v != pv;
+                        const uint32_t at = f ? offf : ftrash;
+                        *(lds_u32)(uintptr_t)at = v; *(lds_u32)(uintptr_t)(at + 4u) = pv | tag1;
+                        offf += f ? 8u : 0u;
+                    }
+                    {
+                        const bool g = v != pcv[j];
+                        const uint32_t at = g ? offr : rtrash;
+                        if (ADJ) *(lds_u32)(uintptr_t)at = v;
+                        *(lds_u32)(uintptr_t)(at + RSTRIDE) = pcv[j];
+                        *(lds_u32)(uintptr_t)(at + 2u * RSTRIDE) = (lane_c + (uint32_t)j) | rowcode;
+                        offr += g ? 4u : 0u;
+                    }
+#else
                     if (ADJ && (r > 0 || !EDGE || has_up)) {
                         const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];
                         if (v != pv) {
@@ -750,6 +808,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                         *(lds_u32)(uintptr_t)(offr + 2u * RSTRIDE) = (lane_c + (uint32_t)j) | rowcode;
                         offr += 4u;
                     }
+#endif
                 }
                 if (need_end && lane == 63) {
                     if (ADJ) *(lds_u32)(uintptr_t)offr = INVALID_LABEL;
@@ -768,11 +827,14 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         atomicAdd(&fl[8], (uint32_t)(tk_cmp >> 8)); atomicAdd(&fl[9], (uint32_t)(tk_emit >> 8));
         atomicAdd(&fl[10], (uint32_t)(tk_drain >> 8)); atomicAdd(&fl[11], (uint32_t)(tk_adv >> 8));
         atomicAdd(&fl[12], (uint32_t)((TA_T() - tk_begin) >> 8));
-        atomicAdd(&fl[13], (uint32_t)tk_rows); atomicAdd(&fl[14], (uint32_t)tk_evrows); atomicAdd(&fl[15], (uint32_t)tk_drains);
+        atomicAdd(&fl[13], (uint32_t)(tk_land >> 8)); atomicAdd(&fl[14], (uint32_t)tk_evrows); atomicAdd(&fl[15], (uint32_t)tk_drains);
     }
 #endif
 
     // ---- end of tile: drain the buffers, then the leading one-label rows in one closed form
+#ifdef TA_RECCOUNT
+    if (lane == 0) { atomicAdd(&cold_args(kp)->flags[8], fcount); atomicAdd(&cold_args(kp)->flags[9], rcount); atomicAdd(&cold_args(kp)->flags[10], 1u); }
+#endif
     drain_buffers<ADJ, MOM2, LDS>(kp, S, EDGE, w, lane, fcount, rcount);
     if (__builtin_amdgcn_ballot_w64(bad)) { if (lane == 0) atomicOr(&cold_args(kp)->flags[FLAG_RANGE], 1u); }
     if (lane == 0 && nlead != 0u && first_label != INVALID_LABEL) {

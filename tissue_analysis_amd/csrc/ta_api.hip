@@ -100,6 +100,7 @@ struct ta_ctx {
     uint32_t feature_mask = 0;
     bool extracted = false, checked = false;
     bool exchanged = false;                             // adjacency rebuilt by ta_adjacency_merge_blocks
+    bool shared_packed = false;                         // ... from ta_adjacency_pack_shared blocks: the list is PARTIAL
     bool reduced = false;                               // the bound accumulators hold other ranks' contributions too
     int64_t npairs = 0;
     std::vector<uint64_t> h_keys, h_faces;              // sorted host copy for ta_adjacency_get
@@ -750,6 +751,7 @@ TA_API int ta_extract(ta_ctx* c, uint32_t feature_mask, uint32_t max_label) {
     c->extracted = true;
     c->checked = false;
     c->exchanged = false;
+    c->shared_packed = false;
     c->reduced = false;
     c->host_pairs_ready = false;
     return run_extract(c);
@@ -789,6 +791,14 @@ TA_API int ta_get_labels(ta_ctx* c, uint64_t* count, int32_t* bbox, uint64_t* su
             }
         }
     }
+    return TA_OK;
+}
+
+TA_API int ta_adjacency_scope(ta_ctx* c, int* scope) {
+    if (!c || !scope) return fail(TA_EINVAL, "NULL argument");
+    if (!c->extracted || !(c->feature_mask & TA_F_ADJACENCY))
+        return fail(TA_EINVAL, "no extraction with adjacency has been run on this context");
+    *scope = !c->exchanged ? TA_ADJ_LOCAL : (c->shared_packed ? TA_ADJ_PARTIAL : TA_ADJ_MERGED);
     return TA_OK;
 }
 
@@ -858,9 +868,7 @@ TA_API int ta_timing(ta_ctx* c, double* ms_sweep, double* ms_adjacency, double* 
             TA_HIP(hipEventElapsedTime(&b, ev_b, c->ev[3]));
             TA_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
         }
-    } else if (ms_sweep || ms_adjacency || ms_total) {
-        return fail(TA_EINVAL, "the last extraction recorded no events (TA_OPT_TIMING is 0)");
-    }
+    }      // (else: the last extraction recorded no events -- TA_OPT_TIMING is 0 -- and the durations are answered as zero)
     if (ms_sweep) *ms_sweep = a;
     if (ms_adjacency) *ms_adjacency = b;
     if (ms_total) *ms_total = t;
@@ -1027,6 +1035,7 @@ TA_API int ta_adjacency_pack_shared(ta_ctx* c, void* block_dev, int64_t capacity
                                  (uint64_t)capacity_pairs, 1ull << c->pair_log2);
     TA_HIP(hipGetLastError());
     c->table_clean = false;          // holds this rank's private pairs until ta_adjacency_merge_blocks collects
+    c->shared_packed = true;
     return TA_OK;
 }
 

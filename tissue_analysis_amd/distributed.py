@@ -42,15 +42,18 @@ def to_device_layout(arrays):
     return sums, boxes
 
 
-def from_device_layout(sums, boxes):
+def from_device_layout(sums, boxes, second_moments=True):
+    """Device rows -> the host getters' arrays.  Without TA_F_MOMENT2 the second-moment columns of the device rows are not
+    defined (the rare table-spill path of the sweep leaves cross terms there): they are answered as zero, like
+    ta_get_labels does."""
     sums = np.asarray(sums)
     boxes = np.asarray(boxes)
     present = boxes[:, 0] != INT32_MAX
     bbox = np.full(boxes.shape, -1, dtype=np.int32)
     bbox[present, :3] = boxes[present, :3]
     bbox[present, 3:] = -boxes[present, 3:] + 1
-    return dict(count=sums[:, 0].astype(np.uint64), bbox=bbox, sum1=sums[:, 1:4].astype(np.uint64),
-                sum2=sums[:, 4:10].astype(np.uint64))
+    sum2 = sums[:, 4:10].astype(np.uint64) if second_moments else np.zeros((sums.shape[0], 6), dtype=np.uint64)
+    return dict(count=sums[:, 0].astype(np.uint64), bbox=bbox, sum1=sums[:, 1:4].astype(np.uint64), sum2=sum2)
 
 
 # ------------------------------------------------------------------ collectives (device-agnostic)
@@ -153,11 +156,14 @@ class SlabJob(object):
 
     step() = fused sweep of the local slab (+ halo) into torch-owned accumulators bound to the
     C-ABI context, then (world > 1) the RCCL reduce and the adjacency exchange.  After step() every
-    rank holds the global per-label rows and `ctx.adjacency()` holds the global pairs.
+    rank holds the global per-label rows.
 
     Only the pairs a slab face can split travel (ta_adjacency_pack_shared, on the reduced boxes): after step() the
-    context of each rank holds its PRIVATE pairs plus all ranks' travelling pairs merged, and result_arrays() --
-    collective -- gathers the private lists once, when the global list is actually asked for.
+    context of each rank holds its PRIVATE pairs plus all ranks' travelling pairs merged -- a PARTIAL list
+    (`ctx.adjacency_scope() == ADJ_PARTIAL`; `ctx.adjacency()` refuses to hand it out unless asked with
+    `allow_partial=True`).  The GLOBAL list is assembled by result_arrays() -- collective -- which gathers the private
+    lists once, when the global list is actually asked for; a step therefore does not include that gather (bench.py times
+    it separately as `secondary.global_adjacency_gather_ms`).
 
     In steady state step() only ENQUEUES work (kernels and three collectives on one stream): the
     adjacency travels in fixed-capacity exchange blocks (ta_adjacency_pack_shared / _merge_blocks) whose
@@ -250,18 +256,33 @@ class SlabJob(object):
 
     def _agree_on_capacity(self):
         """One-off and synchronous, after the boxes were reduced: the block capacity from the largest number of pairs
-        any rank has to send (a quarter more, in 1024s)."""
+        any rank has to send (a quarter more, in 1024s).  A rank whose pair list cannot be read (table overflow after
+        the accumulators were reduced, HIP error ...) does not raise alone: its status travels with the count and every
+        rank leaves the collective with the same verdict.  Returns False when the step has to be redone."""
         import torch.distributed as dist
+        from . import _capi
         torch = self._torch
-        plo, phi, _ = self.ctx.adjacency()
         lo, hi = self._slab_planes()
-        excl = slab_exclusive(self.boxes.cpu().numpy(), lo, hi)
-        inside = (plo <= self.max_label) & (phi <= self.max_label)
-        travels = ~inside | ~(excl[np.minimum(plo, self.max_label)] | excl[np.minimum(phi, self.max_label)])
-        t = torch.tensor([int(travels.sum())], dtype=torch.int64, device=self.sums.device)
+        status, err, ntravel = self._OK, None, 0
+        try:
+            plo, phi, _ = self.ctx.adjacency()
+            excl = slab_exclusive(self.boxes.cpu().numpy(), lo, hi)
+            inside = (plo <= self.max_label) & (phi <= self.max_label)
+            travels = ~inside | ~(excl[np.minimum(plo, self.max_label)] | excl[np.minimum(phi, self.max_label)])
+            ntravel = int(travels.sum())
+        except _capi.TissueScanError as e:
+            status = {_capi.TA_ECAPACITY: self._CAPACITY, _capi.TA_ERANGE: self._RANGE}.get(e.code, self._FAILED)
+            err = e
+        t = torch.tensor([ntravel, status], dtype=torch.int64, device=self.sums.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
-        nmax = int(t.item())
+        nmax, status = [int(x) for x in t.tolist()]
+        if status == self._CAPACITY:
+            return False                            # (the failing rank's table has already been grown by the getter)
+        if status != self._OK:
+            self._unverified = False
+            self._raise_collectively(status, err)
         self._cap = max(1024, -(-(nmax + nmax // 4 + 1) // 1024) * 1024)
+        return True
 
     def _exchange_buffers(self):
         import torch.distributed as dist
@@ -302,8 +323,13 @@ class SlabJob(object):
         allreduce_accumulators(self.sums, self.boxes, self.group)
         self.ctx.accumulators_reduced()          # from here on a local re-run would lose the other ranks' rows
         if adj:
-            if self._cap is None:
-                self._agree_on_capacity()
+            if self._cap is None and not self._agree_on_capacity():
+                # a pair table overflowed on some rank after the rows were reduced: every rank redoes the step with the
+                # largest table (the sweep starts from clean accumulators: init is part of ta_extract)
+                self.redo_count += 1
+                if self.redo_count > 8:
+                    raise RuntimeError("adjacency table still overflows after %d attempts" % self.redo_count)
+                return self._step()
             world = self._exchange_buffers()
             self.ctx.adjacency_pack_shared(self._send.data_ptr(), self._cap)
             dist.all_gather_into_tensor(self._recv, self._send, group=self.group)
@@ -368,11 +394,12 @@ class SlabJob(object):
         """Global result in the host-getter layout (memory-axis order)."""
         self.finish()
         self._torch.cuda.synchronize()
-        out = from_device_layout(self.sums.cpu().numpy(), self.boxes.cpu().numpy())
-        out["max_label"] = self.max_label
         from . import _capi
+        out = from_device_layout(self.sums.cpu().numpy(), self.boxes.cpu().numpy(),
+                                 second_moments=bool(_capi.feature_mask(self.features) & _capi.F_MOMENT2))
+        out["max_label"] = self.max_label
         if _capi.feature_mask(self.features) & _capi.F_ADJACENCY:
-            lo, hi, faces = self.ctx.adjacency()
+            lo, hi, faces = self.ctx.adjacency(allow_partial=True)
             if self._adjacency_wanted():
                 lo, hi, faces = self._global_pairs(lo, hi, faces)
         else:
