@@ -17,8 +17,13 @@ Rank 0 prints ONE JSON line (contract in the task description), with extra objec
                   bounded crop of the same volume on this node's host (rank 0, N = 1 only); `best_effort`
                   inside it = the one-pass C restatement on 16 host processes (NOT the reference's algorithm)
   secondary    -- (N = 1) the same volume WITHOUT the ellipsoid mask: tissue everywhere, ~50k labels present,
-                  2.6x the event density of the headline workload; and the headline workload with two steps in flight
-                  (what N > 1 runs), so that a scaling curve compares like with like
+                  2.6x the event density of the headline workload (its fraction is also `roofline.frac_50k_labels`); the
+                  headline workload with two steps in flight (what N > 1 runs), so that a scaling curve compares like with
+                  like; `sorted_adjacency_ms`: what a caller of ta_adjacency_get pays on top of a step (device sort by
+                  (lo, hi) + fetch); `c5_single_gpu`: config C5 (2048^3, 34 GB) on this ONE GPU -- the denominator of
+                  BASELINE.json's ">= 6x at 8 GPUs", since N = 8 runs C5.
+                  (N > 1) `global_adjacency_gather_ms`: one SlabJob.result_arrays(), which assembles the GLOBAL pair list
+                  from the ranks' private lists -- not part of a step (a step leaves private + travelling pairs per rank)
 """
 from __future__ import annotations
 
@@ -228,6 +233,16 @@ def main():
         adj_ms.append(last_ctx().timing()["ms_adjacency"])
     bytes_read = last_ctx().timing()["bytes_read"]
 
+    gather_ms = None
+    if n > 1 and feats & _capi.F_ADJACENCY:
+        # the GLOBAL pair list is not part of a step (ranks keep private + travelling pairs): one collective assembly, timed
+        barrier()
+        t1 = time.perf_counter()
+        arrays = job.result_arrays()
+        barrier()
+        gather_ms = (time.perf_counter() - t1) * 1e3
+        global_pairs = int(arrays["pair_lo"].size)
+        del arrays
     tmax = torch.tensor([dt], dtype=torch.float64, device="cuda:%d" % local_rank)
     if n > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -269,6 +284,13 @@ def main():
                          "adjacency_collect_ms": round(float(np.mean(adj_ms)), 4),
                          "algorithmic_bytes_per_launch": int(bytes_read)},
         }
+        if gather_ms is not None:
+            out["secondary"] = {"global_adjacency_gather_ms": {"value": round(gather_ms, 3), "pairs": global_pairs,
+                                "what": "one SlabJob.result_arrays(): all-gather of the ranks' private pair lists + host merge; "
+                                        "outside the timed steps"}}
+        if n == 1 and not args.no_cpu_baseline:     # (before the secondary figures release the volume)
+            cpu_baseline_result = cpu_baseline(job.owned_view(), (a_hi - a_lo, dims[1], dims[2]), dtype)
+            cpu_baseline_result["best_effort"] = cpu_best_effort(job.owned_view(), (a_hi - a_lo, dims[1], dims[2]), dtype, max_label)
         if n == 1 and not args.no_secondary and not args.config and args.features is None and not args.dims \
                 and not args.no_ellipsoid:
             sec = {}
@@ -307,11 +329,51 @@ def main():
                                     "ms_per_step": round(dt3 / args.steps * 1e3, 4),
                                     "value": round(nvox * args.steps / dt3 / 1e6, 1), "unit": "Mvoxels/s",
                                     "kernel_ms": round(k_ms, 4), "roofline_frac": round(bytes_read / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            out["roofline"]["frac_50k_labels"] = sec["tissue_filled"]["roofline_frac"]
             del vol2, job2
+            # (c) what a caller of the sorted pair list pays on top of a step: ta_adjacency_get = device radix sort by
+            #     (lo, hi) + gather of the face counts + the records to the host (first call after each extraction)
+            job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=a_lo, has_low_halo=bool(halo), max_label=max_label,
+                              features=feats, group=None, device=local_rank)      # (the context is back on the headline volume)
+            ts = []
+            for _ in range(5):
+                job.step()
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                lo_, hi_, _f = ctx.adjacency()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            sec["sorted_adjacency_ms"] = {"value": round(float(np.median(ts)), 4), "pairs": int(lo_.size),
+                                          "what": "ta_adjacency_get after a step: sort by (lo, hi) on the device + fetch"}
+            # (d) config C5 on this one GPU (34 GB): the single-GPU denominator of the 8-GPU target
+            try:
+                c5 = synth.CONFIGS["C5"]
+                d5, t5 = c5["dims"], np.dtype(c5["dtype"])
+                vol5, L5 = dev.synth_slab(ctx, d5, t5, c5["n_cells"], c5["seed"], 0, d5[0], device=local_rank)
+                torch.cuda.synchronize()
+                job5 = tad.SlabJob(ctx, vol5, t5.itemsize, a_origin=0, has_low_halo=False, max_label=L5, features=feats,
+                                   group=None, device=local_rank)
+                for _ in range(2):
+                    job5.step()
+                torch.cuda.synchronize()
+                ctx.set_option(_capi.OPT_TIMING_RING, 5)
+                t1 = time.perf_counter()
+                for _ in range(5):
+                    job5.step()
+                torch.cuda.synchronize()
+                dt5 = (time.perf_counter() - t1) / 5
+                k5 = float(np.mean(ctx.timing_series()))
+                b5 = float(d5[0]) * d5[1] * d5[2] * t5.itemsize
+                sec["c5_single_gpu"] = {"workload": "C5: 2048^3 uint32, 100000 seeds (%d labels present), features=0x%x, one GPU"
+                                                    % (int((job5.result_counts() > 0).sum()), feats),
+                                        "ms_per_step": round(dt5 * 1e3, 4), "value": round(b5 / t5.itemsize / dt5 / 1e6, 1),
+                                        "unit": "Mvoxels/s", "kernel_ms": round(k5, 4),
+                                        "roofline_frac": round(b5 / (k5 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+                del vol5, job5
+            except Exception as e:                      # (a box with less free HBM than 34 GB + tables)
+                sec["c5_single_gpu"] = {"skipped": "%s: %s" % (type(e).__name__, str(e)[:120])}
             out["secondary"] = sec
         if n == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(job.owned_view(), (a_hi - a_lo, dims[1], dims[2]), dtype)
-            out["cpu_baseline"]["best_effort"] = cpu_best_effort(job.owned_view(), (a_hi - a_lo, dims[1], dims[2]), dtype, max_label)
+            out["cpu_baseline"] = cpu_baseline_result
         print(json.dumps(out), flush=True)
     if n > 1:
         dist.barrier()

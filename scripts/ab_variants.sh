@@ -7,7 +7,7 @@ export PYTHONPATH=$PWD
 for v in "$@"; do
   if [ "$v" = base ]; then unset TISSUE_SCAN_LIB; else export TISSUE_SCAN_LIB=$PWD/scratch/lib$v.so; fi
   echo "== $v" >> $OUT
-  python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f --iters 7 --no-check 2>&1 | grep "impl=0" | cut -c1-120 >> $OUT
-  python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f --iters 5 --no-check --no-ellipsoid 2>&1 | grep "impl=0" | sed 's/^/filled /' | cut -c1-128 >> $OUT
+  python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f --iters 7 --no-check 2>&1 | grep "impl=0\|Error\|error" | cut -c1-160 >> $OUT
+  python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f --iters 5 --no-check --no-ellipsoid 2>&1 | grep "impl=0\|Error\|error" | sed 's/^/filled /' | cut -c1-128 >> $OUT
 done
 cat $OUT

@@ -38,9 +38,8 @@ def test_series_keeps_the_last_launches_and_modes_switch_events():
         assert t["ms_total"] >= t["ms_sweep"] > 0 and t["ms_adjacency"] > 0
         ctx.set_option(_capi.OPT_TIMING, 0)
         ctx.extract(_capi.F_ALL, L)
-        with pytest.raises(_capi.TissueScanError) as e:
-            ctx.timing()
-        assert e.value.code == _capi.TA_EINVAL
+        t = ctx.timing()                                                                # no events recorded: zeros, not an error
+        assert t["ms_sweep"] == 0 and t["ms_total"] == 0 and t["ms_adjacency"] == 0 and t["bytes_read"] == vol.size * 4
         assert ctx.timing_series() == []
         counts = ctx.labels()[0]                                                        # results are unaffected
         assert int(counts.sum()) == vol.size
