@@ -50,3 +50,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in text and "from oracle" not in text, f
+
+
+def test_pinned_register_tables_are_the_generators_output():
+    """csrc/ta_pin_tables.inc (the register numbers the plane in flight lands in, literals inside inline asm) is generated:
+    the committed file must be what scripts/gen_pin_tables.py writes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert subprocess.call([sys.executable, os.path.join(root, "scripts", "gen_pin_tables.py"), "--check"]) == 0

@@ -180,3 +180,96 @@ def test_c5_on_one_gpu_identities_windows_and_virtual_slabs():
     merged = onepass.merge(parts)
     for k in KEYS:
         assert np.array_equal(merged[k], whole[k]), "8 slabs vs unsharded: " + k
+
+
+def test_c5_exchange_budget_eight_contexts_on_one_gpu(capsys):
+    """SURVEY.md §8(e) leaves <= 0.25 ms per step for halo + reduce + merge at 8 GPUs.  No 8-GPU node runs this suite, so the
+    exchange step is rehearsed at FULL C5 size on one GPU: eight contexts hold the eight Z-slabs (views of one resident
+    2048^3 volume, halo plane included), each sweeps its slab, the per-label rows are reduced with torch ops in place of the
+    two all-reduces, every context packs the pairs a slab face can split (ta_adjacency_pack_shared), the eight blocks sit in
+    one tensor as an all-gather would leave them, every context merges them.  Checked: private lists + travelling pairs ==
+    the unsharded adjacency, bit for bit.  Printed: per-slab kernel times of the exchange step (a single-GPU ESTIMATE of
+    what each rank would do; the wire time of the collectives is not in it) for DESIGN.md §6."""
+    import torch
+    from tissue_analysis_amd import distributed as tad
+    c = synth.CONFIGS["C5"]
+    dims, dtype = c["dims"], np.dtype(c["dtype"])
+    n0, n1, n2 = dims
+    ctx0 = dev.torch_context(0)
+    vol, L = dev.synth_slab(ctx0, dims, dtype, c["n_cells"], c["seed"])
+    torch.cuda.synchronize()
+    ctx0.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, keep=vol)
+    ctx0.extract(_capi.F_ALL, L)
+    whole = fetch(ctx0, L)
+    ctx0.close()
+    plane_bytes = n1 * n2 * dtype.itemsize
+    world = 8
+
+    def timed(fn):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record(); b.synchronize()
+        return a.elapsed_time(b)
+
+    jobs, sweep_ms = [], []
+    for r in range(world):
+        lo, hi = tad.slab_range(n0, world, r)
+        halo = 1 if lo > 0 else 0
+        ctx = dev.torch_context(0)
+        sums = torch.zeros((L + 1, 10), dtype=torch.int64, device="cuda:0")
+        boxes = torch.zeros((L + 1, 6), dtype=torch.int32, device="cuda:0")
+        ctx.set_volume_device(vol.data_ptr() + (lo - halo) * plane_bytes, dtype.itemsize, (hi - lo + halo, n1, n2), a0_origin=lo,
+                              has_low_halo=bool(halo), keep=vol)
+        ctx.bind_accumulators(sums.data_ptr(), boxes.data_ptr(), L, keep=(sums, boxes))
+        ctx.extract(_capi.F_ALL, L)                                   # warm-up: tables sized
+        sweep_ms.append(timed(lambda: ctx.extract(_capi.F_ALL, L)))
+        jobs.append((ctx, sums, boxes, lo, hi))
+    npairs = [j[0].adjacency_size() for j in jobs]
+    # the two all-reduces, as torch ops on one device (the RCCL wire time is not measured here)
+    tot = torch.stack([j[1] for j in jobs]).sum(dim=0)
+    mn = torch.stack([j[2] for j in jobs]).amin(dim=0)
+    for ctx, s, b, _, _ in jobs:
+        s.copy_(tot); b.copy_(mn)
+        ctx.accumulators_reduced()
+    torch.cuda.synchronize()
+    got = tad.from_device_layout(tot.cpu().numpy(), mn.cpu().numpy())
+    for k in ("count", "bbox", "sum1", "sum2"):
+        assert np.array_equal(got[k], whole[k]), "reduced rows: " + k
+    cap = 1 << 17
+    words = _capi.exchange_words(cap)
+    blocks = torch.empty((world * words,), dtype=torch.int64, device="cuda:0")
+    pack_ms = [timed(lambda: ctx.adjacency_pack_shared(blocks[r * words:(r + 1) * words].data_ptr(), cap))
+               for r, (ctx, _, _, _, _) in enumerate(jobs)]
+    sent = [int(blocks[r * words].item()) for r in range(world)]
+    assert max(sent) <= cap
+    merge_ms = [timed(lambda: ctx.adjacency_merge_blocks(blocks.data_ptr(), world, cap)) for ctx, _, _, _, _ in jobs]
+    # world-size-1 timing of the two in-place reduces' local cost is not a wire time either; the row sizes set the message
+    row_mb = (tot.numel() * 8 + mn.numel() * 4) / 1e6
+    # union of the private lists + the (identical) merged travelling pairs == the unsharded list
+    bx = mn.cpu().numpy()
+    keys_all, faces_all, travelling = [], [], None
+    for ctx, _, _, lo, hi in jobs:
+        plo, phi, pf = ctx.adjacency(allow_partial=True)
+        excl = tad.slab_exclusive(bx, lo, hi)
+        private = excl[plo] | excl[phi]
+        key = (plo.astype(np.int64) << 32) | phi.astype(np.int64)
+        keys_all.append(key[private]); faces_all.append(pf[private])
+        t = (key[~private], pf[~private])
+        if travelling is None:
+            travelling = t
+        else:
+            assert np.array_equal(travelling[0], t[0]) and np.array_equal(travelling[1], t[1])
+    keys = np.concatenate(keys_all + [travelling[0]])
+    faces = np.concatenate(faces_all + [travelling[1]])
+    order = np.argsort(keys, kind="stable")
+    assert np.unique(keys).size == keys.size
+    want_key = (whole["pair_lo"].astype(np.int64) << 32) | whole["pair_hi"].astype(np.int64)
+    assert np.array_equal(keys[order], want_key) and np.array_equal(faces[order], whole["pair_faces"])
+    for ctx, _, _, _, _ in jobs:
+        ctx.close()
+    with capsys.disabled():
+        print("\n[C5 as 8 slabs on one GPU, single-GPU estimate] per slab: sweep %.3f ms (max %.3f), local pairs %d..%d, "
+              "travelling %d..%d of them (%.1f%%), all travelling pairs merged %d; pack_shared %.3f ms (max %.3f), "
+              "merge_blocks of 8 blocks %.3f ms (max %.3f); rows to all-reduce %.1f MB; exchange block %.1f MB per rank"
+              % (float(np.mean(sweep_ms)), max(sweep_ms), min(npairs), max(npairs), min(sent), max(sent),
+                 100.0 * sum(sent) / sum(npairs), travelling[0].size, float(np.mean(pack_ms)), max(pack_ms),
+                 float(np.mean(merge_ms)), max(merge_ms), row_mb, words * 8 / 1e6))

@@ -172,14 +172,36 @@ def _nccl_worker(rank, world, port, dims, n_cells, seed, q):
         got2 = pipe.result_arrays()
         bad += ["pipelined " + k for k in ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces")
                 if not np.array_equal(got2[k], want[k])]
-        q.put((rank, not bad, bad))
+        # the exchange step's three collectives at C5's message sizes (100 001 label rows; a 2^17-pair block per rank), world
+        # size 1: the launch + local cost RCCL adds per step with no wire -- the floor of SURVEY.md §8(e)'s budget
+        rows = 100001
+        sums = torch.zeros((rows, 10), dtype=torch.int64, device="cuda:0")
+        boxes = torch.zeros((rows, 6), dtype=torch.int32, device="cuda:0")
+        words = _capi.exchange_words(1 << 17)
+        send = torch.zeros((words,), dtype=torch.int64, device="cuda:0")
+        recv = torch.zeros((words,), dtype=torch.int64, device="cuda:0")
+
+        def one():
+            tad.allreduce_accumulators(sums, boxes, dist.group.WORLD)
+            dist.all_gather_into_tensor(recv, send, group=dist.group.WORLD)
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(20):
+            one()
+        b.record(); b.synchronize()
+        note = "RCCL at world size 1, C5 message sizes (rows %.1f MB, block %.1f MB): %.3f ms per step for 2 all-reduces + 1 all-gather" % (
+            (sums.numel() * 8 + boxes.numel() * 4) / 1e6, words * 8 / 1e6, a.elapsed_time(b) / 20)
+        q.put((rank, not bad, bad, note))
         pipe.close()
         ctx.close()
     finally:
         dist.destroy_process_group()
 
 
-def test_world_size_one_over_rccl():
+def test_world_size_one_over_rccl(capsys):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29500 + (os.getpid() % 400)
@@ -188,6 +210,8 @@ def test_world_size_one_over_rccl():
     res = q.get(timeout=300)
     p.join(timeout=60)
     assert p.exitcode == 0 and res[1], res
+    with capsys.disabled():
+        print("\n[" + res[3] + "]")
 
 
 def _range_worker(rank, world, port, q):

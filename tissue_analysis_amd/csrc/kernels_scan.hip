@@ -347,7 +347,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // (Loading into ordinary asm outputs does not work: the register allocator copies a loop-carried output at the
 // back edge, i.e. reads it while the load is still in flight; accumulation registers make the compiler split the
 // unified file in halves.)
-// (generated: the register names of the two budgets in use, written out)
 #define TA_PIN_ADJ 104        // kernels with adjacency: 104 compiler-allocated VGPRs + 21 pinned = 125: four waves per SIMD
 #define TA_PIN_MOM 76         // kernels without (rows only: no row above, no voxel to the left): 76 + 16 = 92: five waves
 // amdgpu_num_vgpr is a request the allocator overshoots when it would have to spill: ask for less than the first
@@ -362,116 +361,7 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define TA_CAP_ADJ_PAD 116
 #define TA_CAP_MOM_PAD 76
 template <int BASE> struct Pin;
-template <> struct Pin<104> {
-    template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
-        if (Q == 0) asm volatile("global_load_dwordx4 v[104:107], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
-        else if (Q == 1) asm volatile("global_load_dwordx4 v[108:111], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
-        else if (Q == 2) asm volatile("global_load_dwordx4 v[112:115], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
-        else if (Q == 3) asm volatile("global_load_dwordx4 v[116:119], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
-        else asm volatile("global_load_dwordx4 v[120:123], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
-    }
-    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t voff, const void* sbase) {
-        if (sizeof(T) == 4 && RB == 4) asm volatile("global_load_dword v124, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
-        if (sizeof(T) == 4 && RB != 4) asm volatile("global_load_dword v116, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
-        if (sizeof(T) != 4 && RB == 4) asm volatile("global_load_ushort v124, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
-        if (sizeof(T) != 4 && RB != 4) asm volatile("global_load_ushort v116, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v104", "v105", "v106", "v107", "v108", "v109", "v110", "v111", "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119", "v120", "v121", "v122", "v123", "v124");
-    }
-    template <int RB> static __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {
-        if (RB == 4) {
-            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v104\n" "v_mov_b32 %1, v105\n" "v_mov_b32 %2, v106\n" "v_mov_b32 %3, v107\n" "v_mov_b32 %4, v108\n" "v_mov_b32 %5, v109\n" "v_mov_b32 %6, v110\n" "v_mov_b32 %7, v111\n" "v_mov_b32 %8, v112\n" "v_mov_b32 %9, v113\n" "v_mov_b32 %10, v114\n" "v_mov_b32 %11, v115\n" "v_mov_b32 %12, v116\n" "v_mov_b32 %13, v117\n" "v_mov_b32 %14, v118\n" "v_mov_b32 %15, v119\n" "v_mov_b32 %16, v120\n" "v_mov_b32 %17, v121\n" "v_mov_b32 %18, v122\n" "v_mov_b32 %19, v123\n" "v_mov_b32 %20, v124\n" 
-                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
-                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
-                           "=&v"(raw[RB > 2 ? 2 : 0].x), "=&v"(raw[RB > 2 ? 2 : 0].y), "=&v"(raw[RB > 2 ? 2 : 0].z), "=&v"(raw[RB > 2 ? 2 : 0].w),
-                           "=&v"(raw[RB > 3 ? 3 : 0].x), "=&v"(raw[RB > 3 ? 3 : 0].y), "=&v"(raw[RB > 3 ? 3 : 0].z), "=&v"(raw[RB > 3 ? 3 : 0].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
-                         :: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v104\n" "v_mov_b32 %1, v105\n" "v_mov_b32 %2, v106\n" "v_mov_b32 %3, v107\n" "v_mov_b32 %4, v108\n" "v_mov_b32 %5, v109\n" "v_mov_b32 %6, v110\n" "v_mov_b32 %7, v111\n" "v_mov_b32 %8, v112\n" "v_mov_b32 %9, v113\n" "v_mov_b32 %10, v114\n" "v_mov_b32 %11, v115\n" "v_mov_b32 %12, v116\n" 
-                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
-                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
-                         :: "memory");
-        }
-    }
-};
-template <> struct Pin<120> {
-    template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
-        if (Q == 0) asm volatile("global_load_dwordx4 v[120:123], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
-        else if (Q == 1) asm volatile("global_load_dwordx4 v[124:127], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
-        else if (Q == 2) asm volatile("global_load_dwordx4 v[128:131], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
-        else if (Q == 3) asm volatile("global_load_dwordx4 v[132:135], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
-        else asm volatile("global_load_dwordx4 v[136:139], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
-    }
-    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t voff, const void* sbase) {
-        if (sizeof(T) == 4 && RB == 4) asm volatile("global_load_dword v140, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
-        if (sizeof(T) == 4 && RB != 4) asm volatile("global_load_dword v132, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
-        if (sizeof(T) != 4 && RB == 4) asm volatile("global_load_ushort v140, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
-        if (sizeof(T) != 4 && RB != 4) asm volatile("global_load_ushort v132, %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127", "v128", "v129", "v130", "v131", "v132", "v133", "v134", "v135", "v136", "v137", "v138", "v139", "v140");
-    }
-    template <int RB> static __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {
-        if (RB == 4) {
-            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v120\n" "v_mov_b32 %1, v121\n" "v_mov_b32 %2, v122\n" "v_mov_b32 %3, v123\n" "v_mov_b32 %4, v124\n" "v_mov_b32 %5, v125\n" "v_mov_b32 %6, v126\n" "v_mov_b32 %7, v127\n" "v_mov_b32 %8, v128\n" "v_mov_b32 %9, v129\n" "v_mov_b32 %10, v130\n" "v_mov_b32 %11, v131\n" "v_mov_b32 %12, v132\n" "v_mov_b32 %13, v133\n" "v_mov_b32 %14, v134\n" "v_mov_b32 %15, v135\n" "v_mov_b32 %16, v136\n" "v_mov_b32 %17, v137\n" "v_mov_b32 %18, v138\n" "v_mov_b32 %19, v139\n" "v_mov_b32 %20, v140\n" 
-                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
-                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
-                           "=&v"(raw[RB > 2 ? 2 : 0].x), "=&v"(raw[RB > 2 ? 2 : 0].y), "=&v"(raw[RB > 2 ? 2 : 0].z), "=&v"(raw[RB > 2 ? 2 : 0].w),
-                           "=&v"(raw[RB > 3 ? 3 : 0].x), "=&v"(raw[RB > 3 ? 3 : 0].y), "=&v"(raw[RB > 3 ? 3 : 0].z), "=&v"(raw[RB > 3 ? 3 : 0].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
-                         :: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v120\n" "v_mov_b32 %1, v121\n" "v_mov_b32 %2, v122\n" "v_mov_b32 %3, v123\n" "v_mov_b32 %4, v124\n" "v_mov_b32 %5, v125\n" "v_mov_b32 %6, v126\n" "v_mov_b32 %7, v127\n" "v_mov_b32 %8, v128\n" "v_mov_b32 %9, v129\n" "v_mov_b32 %10, v130\n" "v_mov_b32 %11, v131\n" "v_mov_b32 %12, v132\n" 
-                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
-                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)
-                         :: "memory");
-        }
-    }
-};
-template <> struct Pin<76> {
-    template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
-        if (Q == 0) asm volatile("global_load_dwordx4 v[76:79], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
-        else if (Q == 1) asm volatile("global_load_dwordx4 v[80:83], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
-        else if (Q == 2) asm volatile("global_load_dwordx4 v[84:87], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
-        else asm volatile("global_load_dwordx4 v[88:91], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91");
-    }
-    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t, const void*) {}
-    template <int RB> static __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {
-        if (RB == 4) {
-            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v76\n" "v_mov_b32 %1, v77\n" "v_mov_b32 %2, v78\n" "v_mov_b32 %3, v79\n" "v_mov_b32 %4, v80\n" "v_mov_b32 %5, v81\n" "v_mov_b32 %6, v82\n" "v_mov_b32 %7, v83\n" "v_mov_b32 %8, v84\n" "v_mov_b32 %9, v85\n" "v_mov_b32 %10, v86\n" "v_mov_b32 %11, v87\n" "v_mov_b32 %12, v88\n" "v_mov_b32 %13, v89\n" "v_mov_b32 %14, v90\n" "v_mov_b32 %15, v91\n" 
-                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
-                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
-                           "=&v"(raw[RB > 2 ? 2 : 0].x), "=&v"(raw[RB > 2 ? 2 : 0].y), "=&v"(raw[RB > 2 ? 2 : 0].z), "=&v"(raw[RB > 2 ? 2 : 0].w),
-                           "=&v"(raw[RB > 3 ? 3 : 0].x), "=&v"(raw[RB > 3 ? 3 : 0].y), "=&v"(raw[RB > 3 ? 3 : 0].z), "=&v"(raw[RB > 3 ? 3 : 0].w)
-                         :: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v76\n" "v_mov_b32 %1, v77\n" "v_mov_b32 %2, v78\n" "v_mov_b32 %3, v79\n" "v_mov_b32 %4, v80\n" "v_mov_b32 %5, v81\n" "v_mov_b32 %6, v82\n" "v_mov_b32 %7, v83\n" 
-                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
-                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w)
-                         :: "memory");
-        }
-        (void)upr; (void)l;
-    }
-};
-template <> struct Pin<80> {
-    template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {
-        if (Q == 0) asm volatile("global_load_dwordx4 v[80:83], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
-        else if (Q == 1) asm volatile("global_load_dwordx4 v[84:87], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
-        else if (Q == 2) asm volatile("global_load_dwordx4 v[88:91], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
-        else asm volatile("global_load_dwordx4 v[92:95], %0, %1" :: "v"(voff), "s"(sbase) : "memory", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95");
-    }
-    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t, const void*) {}
-    template <int RB> static __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {
-        if (RB == 4) {
-            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v80\n" "v_mov_b32 %1, v81\n" "v_mov_b32 %2, v82\n" "v_mov_b32 %3, v83\n" "v_mov_b32 %4, v84\n" "v_mov_b32 %5, v85\n" "v_mov_b32 %6, v86\n" "v_mov_b32 %7, v87\n" "v_mov_b32 %8, v88\n" "v_mov_b32 %9, v89\n" "v_mov_b32 %10, v90\n" "v_mov_b32 %11, v91\n" "v_mov_b32 %12, v92\n" "v_mov_b32 %13, v93\n" "v_mov_b32 %14, v94\n" "v_mov_b32 %15, v95\n" 
-                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
-                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w),
-                           "=&v"(raw[RB > 2 ? 2 : 0].x), "=&v"(raw[RB > 2 ? 2 : 0].y), "=&v"(raw[RB > 2 ? 2 : 0].z), "=&v"(raw[RB > 2 ? 2 : 0].w),
-                           "=&v"(raw[RB > 3 ? 3 : 0].x), "=&v"(raw[RB > 3 ? 3 : 0].y), "=&v"(raw[RB > 3 ? 3 : 0].z), "=&v"(raw[RB > 3 ? 3 : 0].w)
-                         :: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)\n" "v_mov_b32 %0, v80\n" "v_mov_b32 %1, v81\n" "v_mov_b32 %2, v82\n" "v_mov_b32 %3, v83\n" "v_mov_b32 %4, v84\n" "v_mov_b32 %5, v85\n" "v_mov_b32 %6, v86\n" "v_mov_b32 %7, v87\n" 
-                         : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),
-                           "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w)
-                         :: "memory");
-        }
-        (void)upr; (void)l;
-    }
-};
+#include "ta_pin_tables.inc"        // Pin<104>, Pin<120>, Pin<76>, Pin<80>: generated by scripts/gen_pin_tables.py
 template <typename T, int VPL>
 __device__ __forceinline__ void unpack_strip(const u32x4& x, uint32_t (&dst)[VPL]) {
     if (sizeof(T) == 4) {
