@@ -39,10 +39,13 @@ def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None
         else:
             job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=lo, has_low_halo=bool(halo), max_label=max_label,
                               features=features, group=dist.group.WORLD, device=0, exchange_capacity=capacity)
+            ctx.extract(features, max_label)          # (a plain sweep first: the exchange resets the diagnostic counters)
+            spills = ctx.debug_counters()["label_spills"]
             job.step()
             job.step()                  # a second step must give the same answer (tables self-clean)
         got = job.result_arrays()
-        spills = ctx.debug_counters()["label_spills"] if depth == 1 else 0
+        if depth > 1:
+            spills = 0
         whole = synth.voronoi_labels(dims, n_cells, seed, dtype)
         want = onepass_c.extract(whole, max_label=max_label)
         if not features & _capi.F_MOMENT2:          # not asked for: answered as zero, whatever the spill paths left in the rows
