@@ -50,23 +50,14 @@ namespace ta {
 #ifndef TA_RDRAIN
 #define TA_RDRAIN 120
 #endif
-// 1 = records are stored WITHOUT touching the exec mask: every lane stores at every compare, a lane whose compare did not
-// fire stores into a trash slot behind the wave's buffer (one v_cndmask on the address instead of s_and_saveexec / s_or /
-// s_cbranch_execz around each store: the sweep issues almost as many scalar as vector instructions)
-#ifndef TA_BRANCHLESS
-#define TA_BRANCHLESS 1
-#endif
-#ifndef TA_RUN2
-#define TA_RUN2 0
-#endif
+// Records are stored WITHOUT touching the exec mask: every lane stores at every compare, a lane whose compare did not fire
+// stores into a trash slot behind the wave's buffer (one v_cndmask on the address instead of s_and_saveexec / s_or /
+// s_cbranch_execz around each store: the sweep issues almost as many scalar as vector instructions; C4 1.34 -> 1.29 ms).
+// (Measured and dropped: the same with the address as `trash + f * distance`, f = min(v ^ pv, 1), i.e. no condition code
+// at all: 1.32 ms; two 64-run passes per drain iteration: needs more than the 104 registers the pinned plane leaves.)
 constexpr int FCAP = TA_FCAP, RCAP = TA_RCAP;           // record capacities of a wave's buffers
 constexpr int FDRAIN = TA_FDRAIN, RDRAIN = TA_RDRAIN;   // drain a buffer before a row once it holds this much
-// where the trash slot of the branch-free stores sits: behind the buffers (1), or in front of them (2: the address of a
-// store is then `trash + f * distance`, f = 0 / 1, without a condition code)
-constexpr int FOFF = TA_BRANCHLESS == 2 ? 1 : 0;        // index of the first face record
-constexpr int FTRASH = TA_BRANCHLESS == 2 ? 0 : FCAP;
-constexpr int RSENT = TA_BRANCHLESS == 2 ? 1 : 0;       // index of the runs' sentinel / carry slot; records follow it
-constexpr int RTRASH = TA_BRANCHLESS == 2 ? 0 : RCAP + 1;
+constexpr int FTRASH = FCAP, RTRASH = RCAP + 1;          // the trash slots of the branch-free stores, behind the buffers
 constexpr uint32_t ROWID_MASK = 0xFFFFFC00u;            // bits of a run code that name the row (b, a, and the zero top bits)
 constexpr uint32_t NO_ROW = 0xFFFFFFFFu;                // code of the sentinel: never equal to a record's row
 
@@ -241,7 +232,7 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
         // two passes of 64 faces per iteration: the home-slot reads of both are in flight together
         for (uint32_t i = 0; i < fcount; i += 128u) {
             const uint32_t idx0 = i + (uint32_t)lane, idx1 = idx0 + 64u;
-            const uint2 rec0 = W.frec[FOFF + (idx0 < (uint32_t)FCAP ? idx0 : 0u)], rec1 = W.frec[FOFF + (idx1 < (uint32_t)FCAP ? idx1 : 0u)];
+            const uint2 rec0 = W.frec[idx0 < (uint32_t)FCAP ? idx0 : 0u], rec1 = W.frec[idx1 < (uint32_t)FCAP ? idx1 : 0u];
             const uint32_t v0 = rec0.x, pv0 = rec0.y & 0x3fffffffu, v1 = rec1.x, pv1 = rec1.y & 0x3fffffffu;
             // records that touch the outside-the-volume filler are dropped; a label the record words cannot
             // carry (>= LABEL_LIMIT) raises FLAG_RANGE through the run record of its own voxel
@@ -255,36 +246,9 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
         }
         fcount = 0u;
     }
-#if TA_RUN2
-    // two passes of 64 runs per iteration, like the faces: the record reads and the home-slot reads of both tables are in
-    // flight together before either record is worked on
-    for (uint32_t i = 0; i < rcount; i += 128u) {
-        const uint32_t idxA = i + (uint32_t)lane, idxB = idxA + 64u;
-        const uint32_t slotA = RSENT + (idxA < (uint32_t)RCAP ? idxA : 0u), slotB = RSENT + (idxB < (uint32_t)RCAP ? idxB : 0u);
-        const uint32_t prevA = W.cqc[slotA], codeA = W.cqc[slotA + 1u], labelA = W.cql[slotA + 1u];
-        const uint32_t prevB = W.cqc[slotB], codeB = W.cqc[slotB + 1u], labelB = W.cql[slotB + 1u];
-        const uint32_t vA = ADJ ? W.cqv[slotA + 1u] : 0u, vB = ADJ ? W.cqv[slotB + 1u] : 0u;
-        const uint32_t loA = labelA < vA ? labelA : vA, hiA = labelA < vA ? vA : labelA;
-        const uint32_t loB = labelB < vB ? labelB : vB, hiB = labelB < vB ? vB : labelB;
-        const uint32_t phA = ADJ ? scan_pair_hash(loA, hiA) : 0u, lhA = scan_label_hash(labelA);
-        const uint32_t phB = ADJ ? scan_pair_hash(loB, hiB) : 0u, lhB = scan_label_hash(labelB);
-        const uint64_t pkA = ADJ ? S.pkeys[phA] : 0ull, pkB = ADJ ? S.pkeys[phB] : 0ull;
-        const uint32_t lkA = S.lkeys[lhA], lkB = S.lkeys[lhB];
-        if (idxA < rcount) {
-            if (ADJ && vA < LABEL_LIMIT && labelA < LABEL_LIMIT) scan_pair_add(kp, S, loA, hiA, 2u, phA, pkA);
-            const uint32_t s = ((prevA ^ codeA) & ROWID_MASK) == 0u ? (prevA & 1023u) : 0u;
-            consume_scan_run<MOM2, LDS>(kp, S, EDGE, labelA, s, codeA, lhA, lkA);
-        }
-        if (idxB < rcount) {
-            if (ADJ && vB < LABEL_LIMIT && labelB < LABEL_LIMIT) scan_pair_add(kp, S, loB, hiB, 2u, phB, pkB);
-            const uint32_t s = ((prevB ^ codeB) & ROWID_MASK) == 0u ? (prevB & 1023u) : 0u;
-            consume_scan_run<MOM2, LDS>(kp, S, EDGE, labelB, s, codeB, lhB, lkB);
-        }
-    }
-#else
     for (uint32_t i = 0; i < rcount; i += 64u) {
         const uint32_t idx = i + (uint32_t)lane;
-        const uint32_t slot = RSENT + (idx < (uint32_t)RCAP ? idx : 0u);
+        const uint32_t slot = idx < (uint32_t)RCAP ? idx : 0u;
         const uint32_t prev = W.cqc[slot], code = W.cqc[slot + 1u], label = W.cql[slot + 1u];
         const uint32_t v = ADJ ? W.cqv[slot + 1u] : 0u;
         // the home slots of both tables are read before either is worked on
@@ -298,11 +262,10 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
             consume_scan_run<MOM2, LDS>(kp, S, EDGE, label, s, code, lh, lk);
         }
     }
-#endif
     if (rcount) {
         // carry: the record that follows (if it belongs to the same row) starts where the last one ended
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane == 0) W.cqc[RSENT] = W.cqc[RSENT + rcount];
+        if (lane == 0) W.cqc[0] = W.cqc[rcount];
         rcount = 0u;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -492,12 +455,12 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #ifdef TA_STAMPS
     uint64_t tk_cmp = 0, tk_emit = 0, tk_drain = 0, tk_adv = 0, tk_land = 0, tk_evrows = 0, tk_drains = 0;
 #endif
-    if (lane == 0) W.cqc[RSENT] = NO_ROW;
+    if (lane == 0) W.cqc[0] = NO_ROW;
     // LDS byte offsets of the wave's buffers (the low half of a flat LDS address is the LDS offset)
-    const uint32_t fbase = (uint32_t)(uintptr_t)&W.frec[FOFF];
-    const uint32_t rbase = (uint32_t)(uintptr_t)&W.cqv[RSENT + 1];
+    const uint32_t fbase = (uint32_t)(uintptr_t)&W.frec[0];
+    const uint32_t rbase = (uint32_t)(uintptr_t)&W.cqv[1];
     constexpr uint32_t RSTRIDE = (RCAP + 2) * 4u;         // bytes between the three run arrays
-    const uint32_t ftrash = (uint32_t)(uintptr_t)&W.frec[FTRASH];   // where the stores of compares that did not fire go (TA_BRANCHLESS)
+    const uint32_t ftrash = (uint32_t)(uintptr_t)&W.frec[FTRASH];   // where the stores of compares that did not fire go
     const uint32_t rtrash = (uint32_t)(uintptr_t)&W.cqv[RTRASH];
 
     // One packed add-scan over the lanes gives every lane the offset of its first record (faces in the low half of
@@ -516,10 +479,8 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             if (TA_ABLATE >= 3) break;
             if (fits) {
                 const uint32_t excl = incl - mine;
-                // LDS address of the lane's next face record, and of its next run record (first array); TA_BRANCHLESS == 2:
-                // their distances from the trash slots
-                const uint32_t offf = (TA_BRANCHLESS == 2 ? fbase - ftrash : fbase) + ((fcount + (excl & 0xffffu)) << 3);
-                const uint32_t offr = (TA_BRANCHLESS == 2 ? rbase - rtrash : rbase) + ((rcount + (excl >> 16)) << 2);
+                const uint32_t offf = fbase + ((fcount + (excl & 0xffffu)) << 3);     // LDS address of the lane's next face record
+                const uint32_t offr = rbase + ((rcount + (excl >> 16)) << 2);         // ... and of its next run record (first array)
                 fcount += rowf; rcount += rowr;
                 if (insel && TA_ABLATE < 2) emit(offf, offr);
                 lo = hi; hi = 64u;
@@ -560,24 +521,10 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                 for (int j = 0; j < VPL; ++j) {
                     uint32_t v = nw[r][j];
                     asm volatile("" : "+v"(v));           // (compare again: see the row emission)
-#if TA_BRANCHLESS == 2
-                    // no condition code either: f = min(v ^ pv, 1); the address is the trash slot (BELOW the buffer) plus
-                    // f times the distance to the lane's next slot
-                    const uint32_t f = min(v ^ cur[r][j], 1u);
-                    const uint32_t at = ftrash + __umul24(f, offf);          // (offf counts from the trash slot here)
-                    *(lds_u32)(uintptr_t)at = v; *(lds_u32)(uintptr_t)(at + 4u) = cur[r][j];
-                    offf += f << 3;
-#elif TA_BRANCHLESS
                     const bool f = v != cur[r][j];
                     const uint32_t at = f ? offf : ftrash;
                     *(lds_u32)(uintptr_t)at = v; *(lds_u32)(uintptr_t)(at + 4u) = cur[r][j];
                     offf += f ? 8u : 0u;
-#else
-                    if (v != cur[r][j]) {
-                        *(lds_u32)(uintptr_t)offf = v; *(lds_u32)(uintptr_t)(offf + 4u) = cur[r][j];
-                        offf += 8u;
-                    }
-#endif
                 }
         });
     };
@@ -615,9 +562,9 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     const uint64_t tk_begin = __builtin_amdgcn_s_memtime();
 #define TA_T() __builtin_amdgcn_s_memtime()
 #endif
-    for (int32_t p = p_lo; p < p_hi; ++p) {
+    // `process_plane(p)`: plane p has landed (interior tiles: in `nraw` / `nup_raw` / `nxt_leftv`; edge tiles: in `nxt`...)
+    auto process_plane = [&](const int32_t p) {
         const uint32_t ploc = (uint32_t)(p - p_lo);
-        // ---- the plane in flight lands (it was issued a whole plane of compute ago); the next one is issued
 #ifdef TA_STAMPS
         const uint64_t t4 = TA_T();
 #endif
@@ -632,11 +579,6 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             for (int j = 0; j < VPL; ++j) up[j] = nxt_up[j];
             if (p + 1 < p_hi) { load_rows(p + 1, nxt); load_halo(p + 1, nxt_up, nxt_leftv); }
         } else {
-            Pin<PINB ? PINB : TA_PIN_ADJ>::template landed<RB>(nraw, nup_raw, nxt_leftv);
-#ifdef TA_STAMPS
-            tk_land += TA_T() - t4;
-#endif
-            if (p + 1 < p_hi) issue_plane();
             uint32_t nw[RB][VPL], nup[VPL];
 #pragma unroll
             for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], nw[r]);
@@ -711,28 +653,6 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                     //  alive from the counting pass across the scan -- and across a drain -- in scarce SGPRs)
                     uint32_t v = cur[r][j];
                     asm volatile("" : "+v"(v));
-#if TA_BRANCHLESS == 2
-#ifndef TA_ABL_NOFACE1
-                    if (ADJ && (r > 0 || !EDGE || has_up))
-#else
-                    if (false)
-#endif
-                    {
-                        const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];
-                        const uint32_t f = min(v ^ pv, 1u);
-                        const uint32_t at = ftrash + __umul24(f, offf);
-                        *(lds_u32)(uintptr_t)at = v; *(lds_u32)(uintptr_t)(at + 4u) = pv | tag1;
-                        offf += f << 3;
-                    }
-                    {
-                        const uint32_t g = min(v ^ pcv[j], 1u);
-                        const uint32_t at = rtrash + __umul24(g, offr);
-                        if (ADJ) *(lds_u32)(uintptr_t)at = v;
-                        *(lds_u32)(uintptr_t)(at + RSTRIDE) = pcv[j];
-                        *(lds_u32)(uintptr_t)(at + 2u * RSTRIDE) = (lane_c + (uint32_t)j) | rowcode;
-                        offr += g << 2;
-                    }
-#elif TA_BRANCHLESS
 #ifndef TA_ABL_NOFACE1
                     if (ADJ && (r > 0 || !EDGE || has_up))
 #else
@@ -753,32 +673,35 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                         *(lds_u32)(uintptr_t)(at + 2u * RSTRIDE) = (lane_c + (uint32_t)j) | rowcode;
                         offr += g ? 4u : 0u;
                     }
-#else
-                    if (ADJ && (r > 0 || !EDGE || has_up)) {
-                        const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];
-                        if (v != pv) {
-                            *(lds_u32)(uintptr_t)offf = v; *(lds_u32)(uintptr_t)(offf + 4u) = pv | tag1;
-                            offf += 8u;
-                        }
-                    }
-                    if (v != pcv[j]) {
-                        if (ADJ) *(lds_u32)(uintptr_t)offr = v;
-                        *(lds_u32)(uintptr_t)(offr + RSTRIDE) = pcv[j];
-                        *(lds_u32)(uintptr_t)(offr + 2u * RSTRIDE) = (lane_c + (uint32_t)j) | rowcode;
-                        offr += 4u;
-                    }
-#endif
                 }
                 if (need_end && lane == 63) {
-                    const uint32_t at = TA_BRANCHLESS == 2 ? rtrash + offr : offr;
-                    if (ADJ) *(lds_u32)(uintptr_t)at = INVALID_LABEL;
-                    *(lds_u32)(uintptr_t)(at + RSTRIDE) = cur[r][VPL - 1];
-                    *(lds_u32)(uintptr_t)(at + 2u * RSTRIDE) = (uint32_t)TC | rowcode;
+                    if (ADJ) *(lds_u32)(uintptr_t)offr = INVALID_LABEL;
+                    *(lds_u32)(uintptr_t)(offr + RSTRIDE) = cur[r][VPL - 1];
+                    *(lds_u32)(uintptr_t)(offr + 2u * RSTRIDE) = (uint32_t)TC | rowcode;
                 }
             });
 #ifdef TA_STAMPS
             tk_emit += TA_T() - t1;
 #endif
+        }
+    };
+    // ---- the planes of the tile: the plane in flight lands (it was issued a whole plane of compute ago), the next one is
+    //      issued into the registers it leaves, the landed one is processed.  (Measured and dropped: TWO planes in flight for
+    //      the two-row tiles of uint16 volumes, in the two halves of the sixteen pinned registers -- C2 stayed at 0.070 ms:
+    //      that kernel is bound by its instructions per voxel, not by the bytes it has in flight.)
+    {
+        for (int32_t p = p_lo; p < p_hi; ++p) {
+            if constexpr (PINB != 0) {
+#ifdef TA_STAMPS
+                const uint64_t t4 = TA_T();
+#endif
+                Pin<PINB ? PINB : TA_PIN_ADJ>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+#ifdef TA_STAMPS
+                tk_land += TA_T() - t4;
+#endif
+                if (p + 1 < p_hi) issue_plane();
+            }
+            process_plane(p);
         }
     }
 #ifdef TA_STAMPS
