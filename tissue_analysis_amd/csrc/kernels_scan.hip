@@ -23,8 +23,8 @@
 //   * records of a row land sorted by column, so a run record only carries the column where its run
 //     ENDS: the consumer takes the start from the record before it (same row) -- no max-scan for run
 //     starts in the producer, no per-compare bookkeeping.
-// Records: faces of axis 0/1 {voxel, neighbour | axis << 30}; runs {right voxel, closing label,
-// k | b << 10 | a << 14} (k = end column of the run = column of the right voxel).
+// Records: faces of axis 0/1 {voxel, neighbour | axis << 30}; runs {closing label, k | b << 10 | a << 14} (k = end column of
+// the run = column of the voxel right of it, whose label is the closing label of the row's NEXT record).
 #include "ta_sweep_common.h"
 
 #include <hip/hip_ext.h>
@@ -44,21 +44,10 @@ namespace ta {
 #ifndef TA_RCAP
 #define TA_RCAP 160
 #endif
-#ifndef TA_FDRAIN
-#define TA_FDRAIN 120
-#endif
-#ifndef TA_RDRAIN
-#define TA_RDRAIN 120
-#endif
-// Records are stored WITHOUT touching the exec mask: every lane stores at every compare, a lane whose compare did not fire
-// stores into a trash slot behind the wave's buffer (one v_cndmask on the address instead of s_and_saveexec / s_or /
-// s_cbranch_execz around each store: the sweep issues almost as many scalar as vector instructions; C4 1.34 -> 1.29 ms).
-// (Measured and dropped: the same with the address as `trash + f * distance`, f = min(v ^ pv, 1), i.e. no condition code
-// at all: 1.32 ms; two 64-run passes per drain iteration: needs more than the 104 registers the pinned plane leaves.)
 constexpr int FCAP = TA_FCAP, RCAP = TA_RCAP;           // record capacities of a wave's buffers
-constexpr int FDRAIN = TA_FDRAIN, RDRAIN = TA_RDRAIN;   // drain a buffer before a row once it holds this much
 constexpr int FTRASH = FCAP, RTRASH = RCAP + 1;          // the trash slots of the branch-free stores, behind the buffers
-constexpr uint32_t ROWID_MASK = 0xFFFFFC00u;            // bits of a run code that name the row (b, a, and the zero top bits)
+constexpr uint32_t ROWID_MASK = 0x7FFFFC00u;            // bits of a run code that name the row (b, a, and the zero bits above)
+constexpr uint32_t ROW_END = 0x80000000u;               // code bit of the record that closes a row's last run (no voxel to its right)
 constexpr uint32_t NO_ROW = 0xFFFFFFFFu;                // code of the sentinel: never equal to a record's row
 
 typedef __attribute__((address_space(3))) uint32_t* lds_u32;
@@ -66,7 +55,7 @@ typedef __attribute__((address_space(3))) uint32_t* lds_u32;
 template <bool ADJ>
 struct __attribute__((aligned(16))) ScanWaveLds {
     uint2 frec[ADJ ? FCAP + 1 : 1];                     // faces of axis 0/1: voxel, neighbour | axis << 30; [FCAP] = trash slot
-    uint32_t cqv[RCAP + 2], cql[RCAP + 2], cqc[RCAP + 2];   // runs; record i lives in slot i + 1, slot 0 = sentinel / carry, slot RCAP + 1 = trash
+    uint32_t cql[RCAP + 2], cqc[RCAP + 2];              // runs; record i lives in slot i + 1, slot 0 = sentinel / carry, slot RCAP + 1 = trash
 };
 
 template <int NW, bool ADJ>
@@ -111,8 +100,21 @@ __device__ __forceinline__ const SweepArgs* kernarg_args(const SweepArgs& by_val
 #endif
 }
 
+// 24-bit multiplies by hand: written with __umul24 the compiler sees that only a few product bits are used and falls back to
+// v_mul_lo_u32 / v_mad_u64_u32 -- quarter-rate instructions -- for the two hashes of every record
+__device__ __forceinline__ uint32_t mul24_const(uint32_t x, uint32_t c) {
+    uint32_t r;
+    asm("v_mul_u32_u24 %0, %1, %2" : "=v"(r) : "s"(c), "v"(x));
+    return r;
+}
+__device__ __forceinline__ uint32_t mad24_const(uint32_t x, uint32_t c, uint32_t acc) {
+    uint32_t r;
+    asm("v_mad_u32_u24 %0, %1, %2, %3" : "=v"(r) : "v"(x), "s"(c), "v"(acc));
+    return r;
+}
+
 __device__ __forceinline__ uint32_t scan_label_hash(uint32_t label) {
-    return (__umul24(label, 0x9E3779u) >> (24 - LSLOTS_LOG2)) & (LSLOTS - 1);
+    return (mul24_const(label, 0x9E3779u) >> (24 - LSLOTS_LOG2)) & (LSLOTS - 1);
 }
 
 // `h`, `k` = the label's home slot and the key read from it: the caller issues that read early, together with the
@@ -165,7 +167,7 @@ __device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S,
 }
 
 __device__ __forceinline__ uint32_t scan_pair_hash(uint32_t lo, uint32_t hi) {
-    const uint32_t h = __umul24(lo, 0x9E3779u) + __umul24(hi, 0x85EBCBu);     // two full-rate 24-bit multiplies, modulo 2^24
+    const uint32_t h = mad24_const(hi, 0x85EBCBu, mul24_const(lo, 0x9E3779u));     // two full-rate 24-bit multiplies, modulo 2^24
     return (h >> (24 - PSLOTS_LOG2)) & (PSLOTS - 1);
 }
 
@@ -224,7 +226,8 @@ __device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S,
 // Drain both buffers of a wave completely, 64 records per pass, every lane busy but in the last pass.
 template <bool ADJ, bool MOM2, typename LDS>
 __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
-                                              const bool EDGE, int w, int lane, uint32_t& fcount, uint32_t& rcount) {
+                                              const bool EDGE, int w, int lane, uint32_t& fcount, uint32_t& rcount,
+                                              const uint32_t lead_label) {
     auto& W = S.wave[w];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (TA_ABLATE >= 1) { fcount = 0u; rcount = 0u; return; }
@@ -246,27 +249,43 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
         }
         fcount = 0u;
     }
-    for (uint32_t i = 0; i < rcount; i += 64u) {
+    // The voxel right of a boundary is read from the record that FOLLOWS it in its row, so a boundary record whose follower
+    // is not in the buffer yet stays behind: the buffers are drained between rows, and then the last record closes a row --
+    // except when a row too big for the buffers is placed a lane range at a time (place_in_pieces).
+    uint32_t keep = 0u;
+    if (ADJ && rcount) keep = (__builtin_amdgcn_readfirstlane((int)W.cqc[rcount]) & ROW_END) ? 0u : 1u;
+    const uint32_t nrun = rcount - keep;
+    for (uint32_t i = 0; i < nrun; i += 64u) {
         const uint32_t idx = i + (uint32_t)lane;
         const uint32_t slot = idx < (uint32_t)RCAP ? idx : 0u;
         const uint32_t prev = W.cqc[slot], code = W.cqc[slot + 1u], label = W.cql[slot + 1u];
-        const uint32_t v = ADJ ? W.cqv[slot + 1u] : 0u;
+        // (the voxel right of the boundary = the label of the run that starts there = the closing label of the next record;
+        //  the record that closes a row has none.  A row WITHOUT a closing record -- one of the tile's leading one-label rows -- can
+        //  still hold the boundary with the tile on the left, at column 0: the voxel right of it is the leading label.)
+        const uint32_t ncode = ADJ ? W.cqc[slot + 2u] : 0u;
+        const uint32_t v = !ADJ ? 0u : (code & ROW_END) ? INVALID_LABEL
+                                     : (((code ^ ncode) & ROWID_MASK) == 0u && idx + 1u < rcount) ? W.cql[slot + 2u] : lead_label;
         // the home slots of both tables are read before either is worked on
         const uint32_t lo = label < v ? label : v, hi = label < v ? v : label;
         const uint32_t ph = ADJ ? scan_pair_hash(lo, hi) : 0u, lh = scan_label_hash(label);
         const uint64_t pk = ADJ ? S.pkeys[ph] : 0ull;
         const uint32_t lk = S.lkeys[lh];
-        if (idx < rcount) {
+        if (idx < nrun) {
             if (ADJ && v < LABEL_LIMIT && label < LABEL_LIMIT) scan_pair_add(kp, S, lo, hi, 2u, ph, pk);
             const uint32_t s = ((prev ^ code) & ROWID_MASK) == 0u ? (prev & 1023u) : 0u;
             consume_scan_run<MOM2, LDS>(kp, S, EDGE, label, s, code, lh, lk);
         }
     }
     if (rcount) {
-        // carry: the record that follows (if it belongs to the same row) starts where the last one ended
+        // carry: the record that follows (if it belongs to the same row) starts where the last consumed one ended; a record
+        // that stays behind moves to the front
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (lane == 0) W.cqc[0] = W.cqc[rcount];
-        rcount = 0u;
+        if (lane == 0) {
+            const uint32_t carry = W.cqc[nrun];
+            if (keep) { const uint32_t kl = W.cql[rcount], kc = W.cqc[rcount]; W.cql[1] = kl; W.cqc[1] = kc; }
+            W.cqc[0] = carry;
+        }
+        rcount = keep;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
@@ -458,16 +477,33 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     if (lane == 0) W.cqc[0] = NO_ROW;
     // LDS byte offsets of the wave's buffers (the low half of a flat LDS address is the LDS offset)
     const uint32_t fbase = (uint32_t)(uintptr_t)&W.frec[0];
-    const uint32_t rbase = (uint32_t)(uintptr_t)&W.cqv[1];
-    constexpr uint32_t RSTRIDE = (RCAP + 2) * 4u;         // bytes between the three run arrays
+    const uint32_t rbase = (uint32_t)(uintptr_t)&W.cql[1];
+    constexpr uint32_t RSTRIDE = (RCAP + 2) * 4u;         // bytes between the two run arrays
     const uint32_t ftrash = (uint32_t)(uintptr_t)&W.frec[FTRASH];   // where the stores of compares that did not fire go
-    const uint32_t rtrash = (uint32_t)(uintptr_t)&W.cqv[RTRASH];
+    const uint32_t rtrash = (uint32_t)(uintptr_t)&W.cql[RTRASH];
 
-    // One packed add-scan over the lanes gives every lane the offset of its first record (faces in the low half of
-    // `cnt`, runs in the high half); the totals say whether the records fit.  One trip, unless they do not: then the
-    // buffers are drained first, and a set too big even for empty buffers (noise, never tissue) goes a lane range at a
-    // time.  `emit(offf, offr)` stores the lane's records at its offsets.
-    auto place_records = [&](const uint32_t cnt, auto&& emit) {
+    // Leading rows of the tile that are one label (the label of its first voxel) from end to end are not records:
+    // they are counted and added in closed form at the end -- that is the whole cost of background.
+    uint32_t first_label = INVALID_LABEL;
+    bool leading = true;
+    uint32_t nlead = 0u;
+    auto drain = [&]() {
+#ifdef TA_STAMPS
+        const uint64_t td0 = __builtin_amdgcn_s_memtime();
+#endif
+#ifdef TA_RECCOUNT
+        if (lane == 0) { atomicAdd(&cold_args(kp)->flags[8], fcount); atomicAdd(&cold_args(kp)->flags[9], rcount); atomicAdd(&cold_args(kp)->flags[10], 1u); }
+#endif
+        drain_buffers<ADJ, MOM2, LDS>(kp, S, EDGE, w, lane, fcount, rcount, first_label);
+#ifdef TA_STAMPS
+        tk_drain += __builtin_amdgcn_s_memtime() - td0; tk_drains += 1;
+#endif
+    };
+    // A set of records too big even for empty buffers (a flat wall between two planes: up to RB * VPL faces per lane; noise)
+    // goes a lane range at a time: halve the range until its records fit, place them, go on with the rest; the buffers are
+    // drained whenever the next range does not fit behind what they hold (a boundary record whose follower has not been
+    // placed yet stays behind in a drain, see drain_buffers).
+    auto place_in_pieces = [&](const uint32_t cnt, auto&& emit) {
         uint32_t lo = 0u, hi = 64u;
         for (;;) {
             const bool insel = ((uint32_t)lane - lo) < (hi - lo);
@@ -475,58 +511,67 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             const uint32_t incl = wave_scan_add(mine);
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             const uint32_t rowf = tot & 0xffffu, rowr = tot >> 16;
-            const bool fits = fcount + rowf <= (uint32_t)FCAP && rcount + rowr <= (uint32_t)RCAP;
-            if (TA_ABLATE >= 3) break;
-            if (fits) {
-                const uint32_t excl = incl - mine;
-                const uint32_t offf = fbase + ((fcount + (excl & 0xffffu)) << 3);     // LDS address of the lane's next face record
-                const uint32_t offr = rbase + ((rcount + (excl >> 16)) << 2);         // ... and of its next run record (first array)
-                fcount += rowf; rcount += rowr;
-                if (insel && TA_ABLATE < 2) emit(offf, offr);
-                lo = hi; hi = 64u;
-            } else if ((fcount | rcount) == 0u) {
-                hi = lo + ((hi - lo) >> 1);               // too big even for empty buffers: half the lanes
+            if (fcount + rowf > (uint32_t)FCAP || rcount + rowr > (uint32_t)RCAP) {
+                if (fcount != 0u || rcount > 1u) drain();                  // make room first (one record may stay behind)
+                else hi = lo + ((hi - lo) >> 1);                           // too big even then: half the lanes
                 continue;
             }
-            if (!fits || fcount >= (uint32_t)FDRAIN || rcount >= (uint32_t)RDRAIN) {
-#ifdef TA_STAMPS
-                const uint64_t td0 = __builtin_amdgcn_s_memtime();
-#endif
-#ifdef TA_RECCOUNT
-                if (lane == 0) { atomicAdd(&cold_args(kp)->flags[8], fcount); atomicAdd(&cold_args(kp)->flags[9], rcount); atomicAdd(&cold_args(kp)->flags[10], 1u); }
-#endif
-                drain_buffers<ADJ, MOM2, LDS>(kp, S, EDGE, w, lane, fcount, rcount);
-#ifdef TA_STAMPS
-                tk_drain += __builtin_amdgcn_s_memtime() - td0; tk_drains += 1;
-#endif
-            }
-            if (lo >= 64u) break;
+            const uint32_t excl = incl - mine;
+            if (insel) emit(fbase + ((fcount + (excl & 0xffffu)) << 3), rbase + ((rcount + (excl >> 16)) << 2));
+            fcount += rowf; rcount += rowr;
+            if (hi >= 64u) break;
+            lo = hi; hi = 64u;
         }
     };
-    // A new plane `nw` has landed: its faces with the current plane (axis 0), while both are in registers.
-    auto plane_faces = [&](const uint32_t (&nw)[RB][VPL]) {
-#ifdef TA_ABL_NOFACE0
-        return;                                           // (ablation: results wrong by construction)
-#endif
+    // One packed add-scan over the lanes gives every lane the offset of its first record (faces in the low half of `cnt`,
+    // runs in the high half); the totals say whether the records fit behind what the buffers hold -- if not, the buffers are
+    // drained first.  `emit(offf, offr)` stores the lane's records at its offsets.  The common path is straight-line: scan,
+    // two scalar compares, the stores, one threshold test.
+    auto place_records = [&](const uint32_t cnt, auto&& emit) {
+        const uint32_t incl = wave_scan_add(cnt);
+        const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint32_t rowf = tot & 0xffffu, rowr = tot >> 16;
+        if (TA_ABLATE >= 3) return;
+        // (one drain site, one scalar test: the buffers are drained on the way IN, when these records do not fit behind what
+        //  they hold; draining earlier, at a fill threshold, measured the same from 64 to 190 records)
+        const int32_t over = max((int32_t)(fcount + rowf) - (int32_t)FCAP, (int32_t)(rcount + rowr) - (int32_t)RCAP);
+        if (over > 0) {
+            drain();
+            if (rowf > (uint32_t)FCAP || rcount + rowr > (uint32_t)RCAP) { place_in_pieces(cnt, emit); return; }
+        }
+        const uint32_t excl = incl - cnt;
+        const uint32_t offf = fbase + ((fcount + (excl & 0xffffu)) << 3);     // LDS address of the lane's next face record
+        const uint32_t offr = rbase + ((rcount + (excl >> 16)) << 2);         // ... and of its next run record (first array)
+        fcount += rowf; rcount += rowr;
+        if (TA_ABLATE < 2) emit(offf, offr);
+    };
+    // A new plane has landed: its faces with the plane before it (axis 0) are counted and stored TOGETHER with the events of
+    // its first row -- one scan of the lanes' counts instead of two (`old` = the plane before, kept until that row is done).
+    uint32_t old[RB][VPL];
+    auto count_plane_faces = [&]() {
         uint32_t cf = 0u;
+#ifndef TA_ABL_NOFACE0
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
-            for (int j = 0; j < VPL; ++j) cf += (nw[r][j] != cur[r][j]) ? 1u : 0u;
-        if (__builtin_amdgcn_ballot_w64(cf != 0u) == 0ull) return;
-        place_records(cf, [&](uint32_t offf, uint32_t) {
+            for (int j = 0; j < VPL; ++j) cf += (cur[r][j] != old[r][j]) ? 1u : 0u;
+#endif
+        return cf;
+    };
+    auto emit_plane_faces = [&](uint32_t& offf) {
+#ifndef TA_ABL_NOFACE0
 #pragma unroll
-            for (int r = 0; r < RB; ++r)
+        for (int r = 0; r < RB; ++r)
 #pragma unroll
-                for (int j = 0; j < VPL; ++j) {
-                    uint32_t v = nw[r][j];
-                    asm volatile("" : "+v"(v));           // (compare again: see the row emission)
-                    const bool f = v != cur[r][j];
-                    const uint32_t at = f ? offf : ftrash;
-                    *(lds_u32)(uintptr_t)at = v; *(lds_u32)(uintptr_t)(at + 4u) = cur[r][j];
-                    offf += f ? 8u : 0u;
-                }
-        });
+            for (int j = 0; j < VPL; ++j) {
+                uint32_t v = cur[r][j];
+                asm volatile("" : "+v"(v));               // (compare again: see the row emission)
+                const bool f = v != old[r][j];
+                const uint32_t at = f ? offf : ftrash;
+                *(lds_u32)(uintptr_t)at = v; *(lds_u32)(uintptr_t)(at + 4u) = old[r][j];
+                offf += f ? 8u : 0u;
+            }
+#endif
     };
 
     // ---- prologue: the plane before the tile (another tile's, or the slab's halo plane) only gives faces
@@ -552,11 +597,6 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         }
         issue_plane();
     }
-    // Leading rows of the tile that are one label (the label of its first voxel) from end to end are not records:
-    // they are counted and added in closed form at the end -- that is the whole cost of background.
-    uint32_t first_label = INVALID_LABEL;
-    bool leading = true;
-    uint32_t nlead = 0u;
 
 #ifdef TA_STAMPS
     const uint64_t tk_begin = __builtin_amdgcn_s_memtime();
@@ -569,11 +609,10 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         const uint64_t t4 = TA_T();
 #endif
         if constexpr (PINB == 0) {
-            if (ADJ && (p > p_lo || has_prev)) plane_faces(nxt);
 #pragma unroll
             for (int r = 0; r < RB; ++r)
 #pragma unroll
-                for (int j = 0; j < VPL; ++j) cur[r][j] = nxt[r][j];
+                for (int j = 0; j < VPL; ++j) { old[r][j] = cur[r][j]; cur[r][j] = nxt[r][j]; }
             leftv = nxt_leftv;
 #pragma unroll
             for (int j = 0; j < VPL; ++j) up[j] = nxt_up[j];
@@ -584,11 +623,10 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], nw[r]);
             if (ADJ) unpack_strip<T, VPL>(nup_raw, nup);
             pad_plane(nw, nup, nxt_leftv);
-            if (ADJ && (p > p_lo || has_prev)) plane_faces(nw);
 #pragma unroll
             for (int r = 0; r < RB; ++r)
 #pragma unroll
-                for (int j = 0; j < VPL; ++j) cur[r][j] = nw[r][j];
+                for (int j = 0; j < VPL; ++j) { old[r][j] = cur[r][j]; cur[r][j] = nw[r][j]; }
             if (ADJ) {
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) up[j] = nup[j];
@@ -596,6 +634,8 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             leftv = nxt_leftv;
         }
         if (p == p_lo) first_label = __builtin_amdgcn_readfirstlane(cur[0][0]);
+        const bool with_plane_faces = ADJ && (p > p_lo || has_prev);
+        const uint32_t cf_plane = with_plane_faces ? count_plane_faces() : 0u;
 #ifdef TA_STAMPS
         tk_adv += TA_T() - t4;
 #endif
@@ -623,6 +663,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #ifdef TA_ABL_NOFACE1
             cf = 0u;                                      // (ablation: results wrong by construction)
 #endif
+            if (ADJ && r == 0) cf += cf_plane;            // the plane's axis-0 faces ride on its first row's scan
             const uint32_t rowlab = __builtin_amdgcn_readfirstlane(cur[r][0]);
             const bool uniform = inner == 0ull;
             bool need_end;                                // the row's last run closes by a record of lane 63
@@ -647,6 +688,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                 uint32_t rowcode = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bloc << 10) | (ploc << 14)));
                 if (ADJ) asm volatile("" : "+s"(tag1));
                 asm volatile("" : "+s"(rowcode));
+                if (ADJ && r == 0) { if (with_plane_faces) emit_plane_faces(offf); }
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) {
                     // (an opaque copy: the compares are done again here instead of keeping a dozen 64-bit lane masks
@@ -668,16 +710,14 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                     {
                         const bool g = v != pcv[j];
                         const uint32_t at = g ? offr : rtrash;
-                        if (ADJ) *(lds_u32)(uintptr_t)at = v;
-                        *(lds_u32)(uintptr_t)(at + RSTRIDE) = pcv[j];
-                        *(lds_u32)(uintptr_t)(at + 2u * RSTRIDE) = (lane_c + (uint32_t)j) | rowcode;
+                        *(lds_u32)(uintptr_t)at = pcv[j];
+                        *(lds_u32)(uintptr_t)(at + RSTRIDE) = (lane_c + (uint32_t)j) | rowcode;
                         offr += g ? 4u : 0u;
                     }
                 }
                 if (need_end && lane == 63) {
-                    if (ADJ) *(lds_u32)(uintptr_t)offr = INVALID_LABEL;
-                    *(lds_u32)(uintptr_t)(offr + RSTRIDE) = cur[r][VPL - 1];
-                    *(lds_u32)(uintptr_t)(offr + 2u * RSTRIDE) = (uint32_t)TC | rowcode;
+                    *(lds_u32)(uintptr_t)offr = cur[r][VPL - 1];
+                    *(lds_u32)(uintptr_t)(offr + RSTRIDE) = (uint32_t)TC | rowcode | ROW_END;
                 }
             });
 #ifdef TA_STAMPS
@@ -715,10 +755,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #endif
 
     // ---- end of tile: drain the buffers, then the leading one-label rows in one closed form
-#ifdef TA_RECCOUNT
-    if (lane == 0) { atomicAdd(&cold_args(kp)->flags[8], fcount); atomicAdd(&cold_args(kp)->flags[9], rcount); atomicAdd(&cold_args(kp)->flags[10], 1u); }
-#endif
-    drain_buffers<ADJ, MOM2, LDS>(kp, S, EDGE, w, lane, fcount, rcount);
+    drain();
     if (__builtin_amdgcn_ballot_w64(bad)) { if (lane == 0) atomicOr(&cold_args(kp)->flags[FLAG_RANGE], 1u); }
     if (lane == 0 && nlead != 0u && first_label != INVALID_LABEL) {
         // rows in (plane, row) order: P full planes of RB rows, then R rows of plane P
