@@ -227,7 +227,7 @@ __device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S,
 template <bool ADJ, bool MOM2, typename LDS>
 __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
                                               const bool EDGE, int w, int lane, uint32_t& fcount, uint32_t& rcount,
-                                              const uint32_t lead_label) {
+                                              const uint32_t lead_label, const bool may_keep) {
     auto& W = S.wave[w];
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (TA_ABLATE >= 1) { fcount = 0u; rcount = 0u; return; }
@@ -252,8 +252,10 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
     // The voxel right of a boundary is read from the record that FOLLOWS it in its row, so a boundary record whose follower
     // is not in the buffer yet stays behind: the buffers are drained between rows, and then the last record closes a row --
     // except when a row too big for the buffers is placed a lane range at a time (place_in_pieces).
+    // (`may_keep`: only there.  Everywhere else a last record without a follower is complete as it is: the boundary with the
+    //  tile on the left in a row that has no closing record.)
     uint32_t keep = 0u;
-    if (ADJ && rcount) keep = (__builtin_amdgcn_readfirstlane((int)W.cqc[rcount]) & ROW_END) ? 0u : 1u;
+    if (ADJ && may_keep && rcount) keep = (__builtin_amdgcn_readfirstlane((int)W.cqc[rcount]) & ROW_END) ? 0u : 1u;
     const uint32_t nrun = rcount - keep;
     for (uint32_t i = 0; i < nrun; i += 64u) {
         const uint32_t idx = i + (uint32_t)lane;
@@ -487,14 +489,14 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     uint32_t first_label = INVALID_LABEL;
     bool leading = true;
     uint32_t nlead = 0u;
-    auto drain = [&]() {
+    auto drain = [&](const bool may_keep) {
 #ifdef TA_STAMPS
         const uint64_t td0 = __builtin_amdgcn_s_memtime();
 #endif
 #ifdef TA_RECCOUNT
         if (lane == 0) { atomicAdd(&cold_args(kp)->flags[8], fcount); atomicAdd(&cold_args(kp)->flags[9], rcount); atomicAdd(&cold_args(kp)->flags[10], 1u); }
 #endif
-        drain_buffers<ADJ, MOM2, LDS>(kp, S, EDGE, w, lane, fcount, rcount, first_label);
+        drain_buffers<ADJ, MOM2, LDS>(kp, S, EDGE, w, lane, fcount, rcount, first_label, may_keep);
 #ifdef TA_STAMPS
         tk_drain += __builtin_amdgcn_s_memtime() - td0; tk_drains += 1;
 #endif
@@ -512,7 +514,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             const uint32_t tot = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             const uint32_t rowf = tot & 0xffffu, rowr = tot >> 16;
             if (fcount + rowf > (uint32_t)FCAP || rcount + rowr > (uint32_t)RCAP) {
-                if (fcount != 0u || rcount > 1u) drain();                  // make room first (one record may stay behind)
+                if (fcount != 0u || rcount > 1u) drain(true);              // make room first (one record may stay behind)
                 else hi = lo + ((hi - lo) >> 1);                           // too big even then: half the lanes
                 continue;
             }
@@ -536,7 +538,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         //  they hold; draining earlier, at a fill threshold, measured the same from 64 to 190 records)
         const int32_t over = max((int32_t)(fcount + rowf) - (int32_t)FCAP, (int32_t)(rcount + rowr) - (int32_t)RCAP);
         if (over > 0) {
-            drain();
+            drain(false);
             if (rowf > (uint32_t)FCAP || rcount + rowr > (uint32_t)RCAP) { place_in_pieces(cnt, emit); return; }
         }
         const uint32_t excl = incl - cnt;
@@ -755,7 +757,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #endif
 
     // ---- end of tile: drain the buffers, then the leading one-label rows in one closed form
-    drain();
+    drain(false);
     if (__builtin_amdgcn_ballot_w64(bad)) { if (lane == 0) atomicOr(&cold_args(kp)->flags[FLAG_RANGE], 1u); }
     if (lane == 0 && nlead != 0u && first_label != INVALID_LABEL) {
         // rows in (plane, row) order: P full planes of RB rows, then R rows of plane P
