@@ -16,6 +16,22 @@ def run(ctx, vol, impl, features=_capi.F_ALL, tile_planes=None, max_label=None):
     return x.as_arrays()
 
 
+def _half_and_half(shape, dtype):
+    v = np.ones(shape, dtype=dtype)
+    v[:, :, :shape[2] // 2] = 2
+    v[1, 3, shape[2] // 2 + 5:shape[2] // 2 + 9] = 3          # one small cell inside the right half, away from the tile edge
+    return v
+
+
+def _flat_wall(shape, dtype):
+    v = np.ones(shape, dtype=dtype)
+    for r in range(shape[1]):
+        v[:, r, (7 * r) % 50 + 3:100 + r] = 2 + (r % 5)
+        v[:, r, 100 + r:180] = 9
+        v[1::2, r, 180:shape[2] - r] = 11                     # every other plane: 60+ columns x 16 rows change label
+    return v
+
+
 CASES = [
     ("voronoi_u16_small", lambda: voronoi((20, 24, 40), 12, 1, np.uint16)),
     ("voronoi_u16_c64", lambda: voronoi((33, 31, 64), 30, 2, np.uint16)),
@@ -29,6 +45,13 @@ CASES = [
     ("uniform", lambda: np.full((5, 6, 7), 3, dtype=np.uint32)),
     ("flat_2d", lambda: voronoi((30, 40, 1), 10, 9, np.uint16, ellipsoid=False)),
     ("one_plane", lambda: voronoi((1, 40, 300), 10, 10, np.uint32, ellipsoid=False)),
+    # a tile whose ONLY records are the boundaries with the tile on its left (one-label rows need no closing record): the
+    # drain at the end of a tile once kept the last such record for a follower that never comes (found at full C4 size)
+    ("left_boundary_only_u32", lambda: _half_and_half((26, 32, 512), np.uint32)),
+    ("left_boundary_only_u16", lambda: _half_and_half((9, 16, 1024), np.uint16)),
+    # a flat wall between two planes: more axis-0 faces in one wave than its face buffer holds, so the plane's first row is
+    # placed a lane range at a time and a boundary record waits in the buffer for its follower
+    ("flat_wall_between_planes", lambda: _flat_wall((5, 16, 256), np.uint32)),
 ]
 
 
