@@ -15,11 +15,12 @@
 //
 // How the (sparse: ~2 of 64 lanes per compare) events reach the dense 64-wide consumer:
 //   * per row every lane counts its events (one v_addc per compare), ONE packed DPP add-scan over the
-//     lanes gives each lane the offset of its first record, and a firing lane then stores its record at
-//     its own running offset (store + one v_add under the compare's mask).  No per-compare ballot /
-//     mask-prefix / popcount / SGPR cursor arithmetic, no live 64-bit masks;
+//     lanes gives each lane the offset of its first record, and every lane then stores at every compare
+//     without touching the exec mask: at its own running offset when the compare fired, into a trash slot
+//     when it did not.  No per-compare ballot / mask-prefix / popcount / SGPR cursor arithmetic, no live
+//     64-bit masks; the axis-0 faces of a plane ride on the scan of its first row;
 //   * the per-wave buffers are LINEAR and drained completely (no ring wrap arithmetic); the drain is
-//     checked once per row, BEFORE the row is emitted, from the totals the scan produced;
+//     checked once per row, BEFORE the row is emitted, from the totals the scan produced (one scalar test);
 //   * records of a row land sorted by column, so a run record only carries the column where its run
 //     ENDS: the consumer takes the start from the record before it (same row) -- no max-scan for run
 //     starts in the producer, no per-compare bookkeeping.
