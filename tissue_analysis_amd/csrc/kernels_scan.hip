@@ -150,12 +150,13 @@ __device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S,
         uint32_t* box = &S.lbox[slot * 8];
         const uint4 cur = *reinterpret_cast<const uint4*>(box);          // min a,b,c | max a
         const uint2 cur2 = *reinterpret_cast<const uint2*>(box + 4);     // max b,c
-        if (mna < cur.x) atomicMin(box + 0, mna);
-        if (mnb < cur.y) atomicMin(box + 1, mnb);
-        if (mnc < cur.z) atomicMin(box + 2, mnc);
-        if (mxa > cur.w) atomicMax(box + 3, mxa);
-        if (mxb > cur2.x) atomicMax(box + 4, mxb);
-        if (mxc > cur2.y) atomicMax(box + 5, mxc);
+        // (one test for "this contribution extends the box somewhere": six separately guarded atomics are six exec-mask
+        //  round trips per pass, and almost every run lies inside the box its label already has)
+        const bool grows = (mna < cur.x) | (mnb < cur.y) | (mnc < cur.z) | (mxa > cur.w) | (mxb > cur2.x) | (mxc > cur2.y);
+        if (grows) {
+            atomicMin(box + 0, mna); atomicMin(box + 1, mnb); atomicMin(box + 2, mnc);
+            atomicMax(box + 3, mxa); atomicMax(box + 4, mxb); atomicMax(box + 5, mxc);
+        }
     } else {                                       // table full: straight to the global rows
         const SweepArgs* A = cold_args(kp);
         LocalSums Lc;

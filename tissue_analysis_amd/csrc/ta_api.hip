@@ -776,6 +776,20 @@ TA_API int ta_get_labels(ta_ctx* c, uint64_t* count, int32_t* bbox, uint64_t* su
     auto pair_slot = [](int x, int y) { if (x > y) std::swap(x, y); return x == 0 ? y : (x == 1 ? 2 + y : 5); };
     static const int mem_pair[6][2] = {{0, 0}, {0, 1}, {0, 2}, {1, 1}, {1, 2}, {2, 2}};
     const bool mom2 = c->feature_mask & TA_F_MOMENT2;
+    if (c->perm[0] == 0 && c->perm[1] == 1 && c->perm[2] == 2) {
+        // C-ordered input (array axes = memory axes): no permutation, one tight loop per output
+        if (count) for (uint64_t l = 0; l < n; ++l) count[l] = hs[l * ta::NSUM];
+        if (sum1) for (uint64_t l = 0; l < n; ++l) { sum1[3 * l] = hs[l * ta::NSUM + 1]; sum1[3 * l + 1] = hs[l * ta::NSUM + 2]; sum1[3 * l + 2] = hs[l * ta::NSUM + 3]; }
+        if (sum2) {
+            if (mom2) for (uint64_t l = 0; l < n; ++l) memcpy(sum2 + 6 * l, &hs[l * ta::NSUM + 4], 6 * sizeof(uint64_t));
+            else memset(sum2, 0, n * 6 * sizeof(uint64_t));
+        }
+        if (bbox) for (uint64_t l = 0; l < n; ++l) {
+            const bool present = hb[l * 6] != INT32_MAX;
+            for (int k = 0; k < 3; ++k) { bbox[l * 6 + k] = present ? hb[l * 6 + k] : -1; bbox[l * 6 + 3 + k] = present ? (-hb[l * 6 + 3 + k] + 1) : -1; }
+        }
+        return TA_OK;
+    }
     for (uint64_t l = 0; l < n; ++l) {
         if (count) count[l] = hs[l * ta::NSUM];
         if (sum1) for (int k = 0; k < 3; ++k) sum1[l * 3 + c->perm[k]] = hs[l * ta::NSUM + 1 + k];
@@ -844,11 +858,11 @@ TA_API int ta_adjacency_get(ta_ctx* c, uint32_t* lo, uint32_t* hi, uint64_t* fac
         }
         c->host_pairs_ready = true;
     }
-    for (uint64_t i = 0; i < n; ++i) {
-        if (lo) lo[i] = (uint32_t)(c->h_keys[i] >> 32);
-        if (hi) hi[i] = (uint32_t)(c->h_keys[i] & 0xffffffffu);
-        if (faces) for (int k = 0; k < 3; ++k) faces[3 * i + c->perm[k]] = c->h_faces[3 * i + k];
-    }
+    const bool identity = c->perm[0] == 0 && c->perm[1] == 1 && c->perm[2] == 2;
+    if (lo) for (uint64_t i = 0; i < n; ++i) lo[i] = (uint32_t)(c->h_keys[i] >> 32);
+    if (hi) for (uint64_t i = 0; i < n; ++i) hi[i] = (uint32_t)(c->h_keys[i] & 0xffffffffu);
+    if (faces && identity && n) memcpy(faces, c->h_faces.data(), n * 3 * sizeof(uint64_t));      // C-ordered input: a plain copy
+    else if (faces) for (uint64_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) faces[3 * i + c->perm[k]] = c->h_faces[3 * i + k];
     return TA_OK;
 }
 
