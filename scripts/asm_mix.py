@@ -2,7 +2,7 @@
     python scripts/asm_mix.py FILE [mangled-name-substring]"""
 import collections, sys
 asm = open(sys.argv[1]).read()
-want = sys.argv[2] if len(sys.argv) > 2 else "scan_kernelIjLi4ELi4ELb1ELb0E"
+want = sys.argv[2] if len(sys.argv) > 2 else "scan_two_rows_kernelIjLi4ELi2ELb1E"
 start = [i for i in range(len(asm)) if asm.startswith("_ZN2ta", i) and asm[i:i + 200].split(":")[0].find(want) >= 0 and asm[i - 1] == "\n"][0]
 end = asm.index(".Lfunc_end", start)
 cats = collections.Counter()

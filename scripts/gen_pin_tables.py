@@ -15,6 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tissue_analysis_amd", "csrc", "ta_pin_tables.inc")
 TABLES = [(104, True), (120, True), (76, False), (80, False)]      # (first pinned register, with adjacency)
+TWO_ROW_TABLES = [82]           # adjacency, TWO rows per wave only: 13 registers (rows, row above, voxel to the left)
 
 
 def clobbers(base, n):
@@ -68,10 +69,36 @@ def table(base, adj):
     return "\n".join(o)
 
 
+def table_two_rows(base):
+    c = clobbers(base, 13)
+    o = ["template <> struct Pin<%d> {" % base,
+         "    template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {",
+         "        // (Q > 2 is never issued with two rows per wave; the branch exists only because the caller's `if (RB > 2)` is not constexpr)"]
+    for q in range(3):
+        head = "if (Q == %d)" % q if q == 0 else ("else if (Q == %d)" % q if q < 2 else "else")
+        o.append('        %s asm volatile("global_load_dwordx4 v[%d:%d], %%0, %%1" :: "v"(voff), "s"(sbase) : %s);'
+                 % (head, base + 4 * q, base + 4 * q + 3, c))
+    o.append("    }")
+    o.append("    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t voff, const void* sbase) {")
+    o.append('        static_assert(RB == 2, "this budget holds two rows");')
+    o.append('        if (sizeof(T) == 4) asm volatile("global_load_dword v%d, %%0, %%1" :: "v"(voff), "s"(sbase) : %s);' % (base + 12, c))
+    o.append('        else asm volatile("global_load_ushort v%d, %%0, %%1" :: "v"(voff), "s"(sbase) : %s);' % (base + 12, c))
+    o.append("    }")
+    o.append("    template <int RB> static __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {")
+    o.append('        static_assert(RB == 2, "this budget holds two rows");')
+    o.append('        asm volatile("s_waitcnt vmcnt(0)\\n" %s' % movs(base, 13))
+    o.append('                     : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),')
+    o.append('                       "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)')
+    o.append('                     :: "memory");')
+    o.append("    }")
+    o.append("};")
+    return "\n".join(o)
+
+
 def render():
     head = ("// ta_pin_tables.inc -- GENERATED by scripts/gen_pin_tables.py (do not edit; `--check` compares): the hand-pinned landing\n"
             "// registers of the sweep kernels, one Pin<BASE> per VGPR budget, BASE = the first register above amdgpu_num_vgpr.\n")
-    return head + "\n".join(table(b, a) for b, a in TABLES) + "\n"
+    return head + "\n".join([table(b, a) for b, a in TABLES] + [table_two_rows(b) for b in TWO_ROW_TABLES]) + "\n"
 
 
 if __name__ == "__main__":

@@ -6,7 +6,7 @@ import argparse, csv, glob, os, re, collections
 
 ap = argparse.ArgumentParser()
 ap.add_argument("dirs", nargs="+")
-ap.add_argument("--kernel", default="scan_kernel|sweep_kernel|rowrun_kernel")
+ap.add_argument("--kernel", default="scan_kernel|scan_two_rows_kernel|scan_noadj_kernel")
 args = ap.parse_args()
 pat = re.compile(args.kernel)
 for d in args.dirs:

@@ -46,7 +46,7 @@ def _check_pinned(hipcc, verbose=False):
     subprocess.check_call(cmd, cwd=OBJDIR)
     bases = {}
     for line in open(os.path.join(CSRC, "kernels_scan.hip")):
-        m = re.match(r"#define TA_PIN_(ADJ_PAD|MOM_PAD|ADJ|MOM) (\d+)", line)
+        m = re.match(r"#define TA_PIN_(ADJ_PAD|MOM_PAD|ADJ2|ADJ|MOM) (\d+)", line)
         if m:
             bases[m.group(1)] = int(m.group(2))
     reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
@@ -72,6 +72,8 @@ def _check_pinned(hipcc, verbose=False):
                 ranges = [bases["ADJ_PAD"]]
             elif "scan_noadj_kernel" in func:
                 ranges = [bases["MOM"]]
+            elif "scan_two_rows_kernel" in func:
+                ranges = [bases["ADJ2"]]
             elif "scan_kernel" in func:
                 ranges = [bases["ADJ"]]
             else:
@@ -81,7 +83,7 @@ def _check_pinned(hipcc, verbose=False):
                 if any(hi >= b and lo < b + 21 for b in ranges):      # (21 pinned with adjacency, 16 without: the wider check is safe)
                     bad.append("%s:%d: %s" % (func, ln, t))
                     break
-    if bad or len(bases) != 4:
+    if bad or len(bases) != 5:
         raise RuntimeError("compiler-allocated VGPRs reach the hand-pinned registers in kernels_scan.hip:\n  %s"
                            % "\n  ".join(bad[:10]))
 

@@ -40,10 +40,10 @@ namespace ta {
 #define TA_HOT_ADJ 1
 #endif
 #ifndef TA_FCAP
-#define TA_FCAP 256
+#define TA_FCAP 192
 #endif
 #ifndef TA_RCAP
-#define TA_RCAP 160
+#define TA_RCAP 128
 #endif
 constexpr int FCAP = TA_FCAP, RCAP = TA_RCAP;           // record capacities of a wave's buffers
 constexpr int FTRASH = FCAP, RTRASH = RCAP + 1;          // the trash slots of the branch-free stores, behind the buffers
@@ -333,11 +333,19 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // (Loading into ordinary asm outputs does not work: the register allocator copies a loop-carried output at the
 // back edge, i.e. reads it while the load is still in flight; accumulation registers make the compiler split the
 // unified file in halves.)
+#ifndef TA_PIN_ADJ
 #define TA_PIN_ADJ 104        // kernels with adjacency: 104 compiler-allocated VGPRs + 21 pinned = 125: four waves per SIMD
+#endif
 #define TA_PIN_MOM 76         // kernels without (rows only: no row above, no voxel to the left): 76 + 16 = 92: five waves
 // amdgpu_num_vgpr is a request the allocator overshoots when it would have to spill: ask for less than the first
 // pinned register; the build checks the generated code (tissue_analysis_amd/build.py).
+#ifndef TA_CAP_ADJ
 #define TA_CAP_ADJ 100
+#endif
+// uint32 volumes with adjacency run TWO rows per wave (RB = 2: half the plane state of the four-row tiles): 82 compiler-allocated
+// VGPRs + 13 pinned (two rows, the row above, the voxel to the left) = 95: FIVE waves per SIMD
+#define TA_PIN_ADJ2 82
+#define TA_CAP_ADJ2 78
 #define TA_CAP_MOM 72
 // the PADDED kernels (partial tiles of a volume whose rows are 16-byte aligned: interior-style loads, edge-style
 // semantics) carry more state: with adjacency 116 + 21 = 137 (three waves per SIMD), without 80 + 16 = 96 (five, like the
@@ -883,6 +891,12 @@ template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ))) scan_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
     scan_kernel_body<T, VPL, RB, true, MOM2, EDGE, EDGE ? 0 : TA_PIN_ADJ>(A, sp, wg0);
 }
+// the full tiles of a uint32 volume with adjacency: two rows per wave, five waves per SIMD
+template <typename T, int VPL, int RB, bool MOM2>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ2))) scan_two_rows_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+    static_assert(RB == 2 && sizeof(T) == 4, "the 13-register landing zone holds two rows of a uint32 volume");
+    scan_kernel_body<T, VPL, RB, true, MOM2, false, TA_PIN_ADJ2>(A, sp, wg0);
+}
 template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_MOM))) scan_noadj_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
     scan_kernel_body<T, VPL, RB, false, MOM2, EDGE, EDGE ? 0 : TA_PIN_MOM>(A, sp, wg0);
@@ -908,8 +922,12 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_star
     const dim3 block(WAVES * 64);
     hipEvent_t in0 = ev_start, in1 = n_ed ? nullptr : ev_stop;              // interior launch
     hipEvent_t ed0 = n_in ? nullptr : ev_start, ed1 = ev_stop;              // edge launch
-    if (ADJ) {
-        if (n_in) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
+    if constexpr (ADJ) {
+        if constexpr (sizeof(T) == 4 && RB == 2) {
+            if (n_in) hipExtLaunchKernelGGL((scan_two_rows_kernel<T, VPL, RB, MOM2>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
+        } else {
+            if (n_in) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
+        }
         if (n_ed && sp.padded) hipExtLaunchKernelGGL((scan_pad_kernel<T, VPL, RB, MOM2>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
         else if (n_ed) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
     } else {
@@ -919,27 +937,34 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_star
     }
 }
 
-template <typename T, int VPL, int RB>
-static void launch_scan_t(hipStream_t s, const SweepArgs& a, uint32_t fm, hipEvent_t e0, hipEvent_t e1) {
-    const bool adj = fm & 16u, mom2 = fm & 8u;
-    if (adj && mom2)       launch_scan_tt<T, VPL, RB, true, true>(s, a, e0, e1);
-    else if (adj && !mom2) launch_scan_tt<T, VPL, RB, true, false>(s, a, e0, e1);
-    else if (!adj && mom2) launch_scan_tt<T, VPL, RB, false, true>(s, a, e0, e1);
-    else                   launch_scan_tt<T, VPL, RB, false, false>(s, a, e0, e1);
-}
+// Rows per wave: uint16 volumes 2 x 512 columns; uint32 volumes 4 x 256 without adjacency (four rows in flight per wave: the
+// moments-only kernel is bound by the stream) and 2 x 256 with it (half the plane state: 95 VGPRs and 31 KB of LDS make five
+// waves per SIMD of a kernel that is bound by latency at four -- C4 1.13 -> 1.06 ms, tissue-filled 1.51 -> 1.40 ms at 48-plane tiles).
+constexpr int RB32_ADJ = 2, RB32_MOM = 4;
 
-uint64_t sweep_grid_size(const SweepArgs& a, int itemsize) {
-    const ScanSplit sp = itemsize == 2 ? scan_split<8, 2>(a, 2) : scan_split<4, TA_RB32>(a, 4);
+uint64_t sweep_grid_size(const SweepArgs& a, int itemsize, bool adjacency) {
+    const ScanSplit sp = itemsize == 2 ? scan_split<8, 2>(a, 2) : (adjacency ? scan_split<4, RB32_ADJ>(a, 4) : scan_split<4, RB32_MOM>(a, 4));
     return (uint64_t)sp.tiles_c * sp.tiles_b * sp.nbands;
 }
-// measured on C4 (profiles/r02_ablations.txt): shorter tiles = more workgroups to balance over the CUs against more
-// table inits / flushes; 64 planes start to overflow the 128-slot label table
-int sweep_default_tile_planes(bool adjacency) { return adjacency ? 24 : 16; }
+// measured on C4 / C5 (profiles/r03_ablations.txt, gpurun_out/r3_rb2_tp.txt): shorter tiles = more workgroups to balance over
+// the CUs against more table inits / flushes.  The two-row tiles of uint32 volumes with adjacency cover half the rows, so
+// they walk twice the planes for the same voxels per workgroup (40 and 48 measure the same, 24 is 3 % slower, 64 1 %).
+int sweep_default_tile_planes(bool adjacency, int itemsize) { return adjacency ? (itemsize == 4 ? 48 : 24) : 16; }
 int sweep_max_tile_planes() { return MAX_TILE_PLANES; }
 
 void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask, hipEvent_t ev_start, hipEvent_t ev_stop) {
-    if (itemsize == 2) launch_scan_t<uint16_t, 8, 2>(s, a, feature_mask, ev_start, ev_stop);
-    else               launch_scan_t<uint32_t, 4, TA_RB32>(s, a, feature_mask, ev_start, ev_stop);
+    const bool adj = feature_mask & 16u, mom2 = feature_mask & 8u;
+    if (itemsize == 2) {
+        if (adj && mom2)       launch_scan_tt<uint16_t, 8, 2, true, true>(s, a, ev_start, ev_stop);
+        else if (adj)          launch_scan_tt<uint16_t, 8, 2, true, false>(s, a, ev_start, ev_stop);
+        else if (mom2)         launch_scan_tt<uint16_t, 8, 2, false, true>(s, a, ev_start, ev_stop);
+        else                   launch_scan_tt<uint16_t, 8, 2, false, false>(s, a, ev_start, ev_stop);
+    } else {
+        if (adj && mom2)       launch_scan_tt<uint32_t, 4, RB32_ADJ, true, true>(s, a, ev_start, ev_stop);
+        else if (adj)          launch_scan_tt<uint32_t, 4, RB32_ADJ, true, false>(s, a, ev_start, ev_stop);
+        else if (mom2)         launch_scan_tt<uint32_t, 4, RB32_MOM, false, true>(s, a, ev_start, ev_stop);
+        else                   launch_scan_tt<uint32_t, 4, RB32_MOM, false, false>(s, a, ev_start, ev_stop);
+    }
 }
 
 }  // namespace ta

@@ -156,10 +156,10 @@ int run_extract(ta_ctx* c) {
     a.n0 = c->mdims[0]; a.n1 = c->mdims[1]; a.n2 = c->mdims[2];
     a.a_origin = c->a_origin;
     a.first_owned = c->first_owned;
-    a.tile_planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY);
+    a.tile_planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY, c->itemsize);
     if (c->tile_planes <= 0) {
         // automatic: small volumes get shorter tiles until the launch has >= 2048 workgroups (8 per CU)
-        while (a.tile_planes > 8 && ta::sweep_grid_size(a, c->itemsize) < 2048) a.tile_planes /= 2;
+        while (a.tile_planes > 8 && ta::sweep_grid_size(a, c->itemsize, c->feature_mask & TA_F_ADJACENCY) < 2048) a.tile_planes /= 2;
         // volumes whose cells are so small that a tile holds more labels than the workgroup tables (the contributions
         // then spill to global atomics, ~100x dearer) get shorter tiles still: see finish_extract
         for (int k = 0; k < c->auto_tile_shift && a.tile_planes > 1; ++k) a.tile_planes /= 2;
@@ -178,14 +178,14 @@ int run_extract(ta_ctx* c) {
     uint64_t* hot_rows = nullptr;
     uint64_t nwg = 0;
     if (c->impl == 0) {           // the sweep keeps a private row per workgroup for the hot label
-        nwg = ta::sweep_grid_size(a, c->itemsize);
+        nwg = ta::sweep_grid_size(a, c->itemsize, c->feature_mask & TA_F_ADJACENCY);
         int rc0 = c->hot_rows.reserve(nwg * ta::HOTW * 8);
         if (rc0 != TA_OK) return rc0;
         hot_rows = (uint64_t*)c->hot_rows.p;
     }
 
     const bool adj = c->feature_mask & TA_F_ADJACENCY;
-    c->last_grid = ta::sweep_grid_size(a, c->itemsize);
+    c->last_grid = ta::sweep_grid_size(a, c->itemsize, c->feature_mask & TA_F_ADJACENCY);
     // A hipEventRecord costs ~4 us of queue time: by default only the sweep kernel is bracketed (TA_OPT_TIMING)
     const size_t nslots = c->ring.size() / 2;
     hipEvent_t ev_a = nullptr, ev_b = nullptr;
@@ -415,7 +415,7 @@ TA_API int ta_ctx_get_option(ta_ctx* c, int key, int64_t* value) {
         case TA_OPT_VOLUME_SLACK: *value = c->volume_slack; return TA_OK;
         case TA_OPT_TIMING: *value = c->timing; return TA_OK;
         case TA_OPT_TIMING_RING: *value = (int64_t)(c->ring.size() / 2); return TA_OK;
-        case TA_OPT_TILE_PLANES: *value = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY); return TA_OK;
+        case TA_OPT_TILE_PLANES: *value = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY, c->itemsize); return TA_OK;
         case TA_OPT_PAIR_SLOTS: *value = c->pkeys.p ? c->pair_log2 : c->opt_pair_log2; return TA_OK;
         default: return fail(TA_EINVAL, "unknown option key %d", key);
     }

@@ -13,9 +13,6 @@ namespace ta {
 #ifndef TA_WAVES
 #define TA_WAVES 4
 #endif
-#ifndef TA_RB32
-#define TA_RB32 4
-#endif
 #ifndef TA_PSLOTS
 #define TA_PSLOTS 512
 #endif
