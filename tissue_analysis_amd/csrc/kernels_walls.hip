@@ -339,6 +339,19 @@ __global__ void __launch_bounds__(256) wall_scan_apply_kernel(const uint32_t* co
     }
 }
 
+// the same three kernels as a general exclusive scan of uint32 counts (the adjacency sort buckets its pairs with it)
+uint64_t scan_u32_scratch_bytes(uint64_t n) { return ((n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + 1) * 8 + 16; }
+
+void launch_scan_u32_exclusive(hipStream_t s, const uint32_t* counts, uint64_t n, void* scratch, uint64_t* offsets) {
+    if (n == 0) return;
+    const uint64_t blocks = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+    uint64_t* block_sums = (uint64_t*)scratch;
+    uint64_t* total = block_sums + blocks;
+    hipLaunchKernelGGL(wall_scan_sums_kernel, dim3((unsigned)blocks), dim3(256), 0, s, counts, n, block_sums);
+    hipLaunchKernelGGL(wall_scan_top_kernel, dim3(1), dim3(256), 0, s, block_sums, blocks, total);
+    hipLaunchKernelGGL(wall_scan_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, s, counts, n, block_sums, offsets);
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------
 static int wall_rows_per_wave(int64_t n1) { return n1 < 16 ? (int)(n1 > 0 ? n1 : 1) : 16; }
 

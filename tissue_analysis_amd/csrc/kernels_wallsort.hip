@@ -55,43 +55,4 @@ hipError_t launch_wall_group_by_pair(hipStream_t s, const uint32_t* pairs, const
     return hipGetLastError();
 }
 
-// ---- the adjacency list sorted by (lo, hi) on the device (ta_adjacency_get used to std::sort ~10^5 records) ------------
-__global__ void __launch_bounds__(256) iota_kernel(uint32_t* index, uint64_t n) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) index[i] = (uint32_t)i;
-}
-
-__global__ void __launch_bounds__(256) faces_gather_kernel(const uint64_t* faces, const uint32_t* index, uint64_t n, uint64_t* out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t s = 3ull * index[i];
-        out[3 * i + 0] = faces[s + 0]; out[3 * i + 1] = faces[s + 1]; out[3 * i + 2] = faces[s + 2];
-    }
-}
-
-uint64_t pairs_sort_temp_bytes(uint64_t n) {
-    size_t bytes = 0;
-    hipcub::DoubleBuffer<uint64_t> dk(nullptr, nullptr);
-    hipcub::DoubleBuffer<uint32_t> dv(nullptr, nullptr);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dk, dv, (int64_t)n, 0, 64, nullptr);
-    return (uint64_t)bytes;
-}
-
-// keys0 holds the n keys on entry (it is overwritten); the sorted keys end up in *keys_sorted (keys0 or keys1), the faces
-// in that order in faces_out.  n < 2^32.  Only enqueues work.
-hipError_t launch_pairs_sort(hipStream_t s, uint64_t* keys0, uint64_t* keys1, uint32_t* index0, uint32_t* index1, const uint64_t* faces,
-                             uint64_t n, void* temp, uint64_t temp_bytes, uint64_t** keys_sorted, uint64_t* faces_out) {
-    *keys_sorted = keys0;
-    if (n == 0) return hipSuccess;
-    unsigned blocks = (unsigned)((n + 255) / 256);
-    if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(iota_kernel, dim3(blocks), dim3(256), 0, s, index0, n);
-    hipcub::DoubleBuffer<uint64_t> dk(keys0, keys1);
-    hipcub::DoubleBuffer<uint32_t> dv(index0, index1);
-    size_t bytes = (size_t)temp_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, bytes, dk, dv, (int64_t)n, 0, 64, s);
-    if (e != hipSuccess) return e;
-    *keys_sorted = dk.Current();
-    hipLaunchKernelGGL(faces_gather_kernel, dim3(blocks), dim3(256), 0, s, faces, dv.Current(), n, faces_out);
-    return hipGetLastError();
-}
-
 }  // namespace ta

@@ -50,6 +50,24 @@ struct DevBuf {
     void release() { if (p) (void)hipFree(p); p = nullptr; bytes = 0; }
 };
 
+// page-locked host memory (grow-only): device-to-host copies into it run at PCIe speed, into a std::vector they are staged
+struct PinnedBuf {
+    void* p = nullptr;
+    uint64_t bytes = 0;
+    int reserve(uint64_t need) {
+        if (need <= bytes) return TA_OK;
+        if (p) { (void)hipHostFree(p); p = nullptr; bytes = 0; }
+        if (hipHostMalloc(&p, need ? need : 16, hipHostMallocDefault) != hipSuccess) {
+            (void)hipGetLastError();
+            p = nullptr;
+            return fail(TA_ENOMEM, "hipHostMalloc of %llu bytes failed", (unsigned long long)need);
+        }
+        bytes = need;
+        return TA_OK;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; bytes = 0; }
+};
+
 }  // namespace
 
 struct ta_ctx {
@@ -103,7 +121,7 @@ struct ta_ctx {
     bool shared_packed = false;                         // ... from ta_adjacency_pack_shared blocks: the list is PARTIAL
     bool reduced = false;                               // the bound accumulators hold other ranks' contributions too
     int64_t npairs = 0;
-    std::vector<uint64_t> h_keys, h_faces;              // sorted host copy for ta_adjacency_get
+    PinnedBuf h_pairs;                                  // sorted host copy for ta_adjacency_get: keys u64[n], then faces u64[n][3]
     bool host_pairs_ready = false;
 };
 
@@ -340,7 +358,7 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     c->owned_vol.release(); c->own_sums.release(); c->own_boxes.release();
     c->pkeys.release(); c->pfaces.release(); c->out_keys.release(); c->out_faces.release();
     c->small.release();
-    c->hot_rows.release(); c->sort_buf.release();
+    c->hot_rows.release(); c->sort_buf.release(); c->h_pairs.release();
     c->wall_counts.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
@@ -832,37 +850,35 @@ TA_API int ta_adjacency_get(ta_ctx* c, uint32_t* lo, uint32_t* hi, uint64_t* fac
     if ((rc = finish_extract(c)) != TA_OK) return rc;
     const uint64_t n = (uint64_t)c->npairs;
     if (!c->host_pairs_ready) {
-        try { c->h_keys.resize(n); c->h_faces.resize(n * 3); }
-        catch (...) { return fail(TA_ENOMEM, "out of host memory"); }
+        if ((rc = c->h_pairs.reserve(n * 32 + 16)) != TA_OK) return rc;
         if (n) {
-            // sorted by (lo, hi) on the device: stable radix sort of the keys with the record index as value, then a gather
-            // of the face counts (a std::sort of ~10^5 records used to cost more than the sweep)
+            // sorted by (lo, hi) on the device (kernels_pairsort.hip: counting sort over the label rows, rank inside a bucket;
+            // a std::sort of ~10^5 records used to cost more than the sweep, a 64-bit library radix sort 0.45 ms)
             if (n >= (1ull << 32)) return fail(TA_EINVAL, "too many pairs (%llu)", (unsigned long long)n);
-            const uint64_t temp_bytes = ta::pairs_sort_temp_bytes(n);
-            const uint64_t kb = n * 8, ib = (n * 4 + 15) & ~15ull;
+            const uint64_t kb = n * 8;
             DevBuf& buf = c->sort_buf;
-            if ((rc = buf.reserve(2 * kb + 2 * ib + n * 24 + temp_bytes + 64)) != TA_OK) return rc;
+            if ((rc = buf.reserve(kb + n * 24 + ta::pairs_sort_scratch_bytes(n, c->max_label) + 64)) != TA_OK) return rc;
             char* p = (char*)buf.p;
-            uint64_t* k0 = (uint64_t*)p; p += kb;
-            uint64_t* k1 = (uint64_t*)p; p += kb;
-            uint32_t* i0 = (uint32_t*)p; p += ib;
-            uint32_t* i1 = (uint32_t*)p; p += ib;
+            uint64_t* ks = (uint64_t*)p; p += kb;
             uint64_t* fo = (uint64_t*)p; p += n * 24;
-            uint64_t* ks = nullptr;
-            hipError_t e = hipMemcpyAsync(k0, c->out_keys.p, kb, hipMemcpyDeviceToDevice, c->stream);
-            if (e == hipSuccess) e = ta::launch_pairs_sort(c->stream, k0, k1, i0, i1, (const uint64_t*)c->out_faces.p, n, p, temp_bytes, &ks, fo);
-            if (e == hipSuccess) e = hipMemcpyAsync(c->h_keys.data(), ks, kb, hipMemcpyDeviceToHost, c->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(c->h_faces.data(), fo, n * 24, hipMemcpyDeviceToHost, c->stream);
+            const bool has_voxel = c->vol && c->mdims[0] - c->first_owned > 0 && c->mdims[1] > 0 && c->mdims[2] > 0;
+            hipError_t e = ta::launch_pairs_sort(c->stream, (const uint64_t*)c->out_keys.p, (const uint64_t*)c->out_faces.p, n, c->max_label,
+                                                 p, ks, fo, has_voxel ? c->vol : nullptr, c->itemsize,
+                                                 (int64_t)c->first_owned * c->mdims[1] * c->mdims[2]);
+            // (keys and faces sit back to back in the sort's output: one copy)
+            if (e == hipSuccess) e = hipMemcpyAsync(c->h_pairs.p, ks, n * 32, hipMemcpyDeviceToHost, c->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
             if (e != hipSuccess) return fail(TA_EHIP, "adjacency sort: %s", hipGetErrorString(e));
         }
         c->host_pairs_ready = true;
     }
     const bool identity = c->perm[0] == 0 && c->perm[1] == 1 && c->perm[2] == 2;
-    if (lo) for (uint64_t i = 0; i < n; ++i) lo[i] = (uint32_t)(c->h_keys[i] >> 32);
-    if (hi) for (uint64_t i = 0; i < n; ++i) hi[i] = (uint32_t)(c->h_keys[i] & 0xffffffffu);
-    if (faces && identity && n) memcpy(faces, c->h_faces.data(), n * 3 * sizeof(uint64_t));      // C-ordered input: a plain copy
-    else if (faces) for (uint64_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) faces[3 * i + c->perm[k]] = c->h_faces[3 * i + k];
+    const uint64_t* h_keys = (const uint64_t*)c->h_pairs.p;
+    const uint64_t* h_faces = h_keys + n;
+    if (lo) for (uint64_t i = 0; i < n; ++i) lo[i] = (uint32_t)(h_keys[i] >> 32);
+    if (hi) for (uint64_t i = 0; i < n; ++i) hi[i] = (uint32_t)(h_keys[i] & 0xffffffffu);
+    if (faces && identity && n) memcpy(faces, h_faces, n * 3 * sizeof(uint64_t));      // C-ordered input: a plain copy
+    else if (faces) for (uint64_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) faces[3 * i + c->perm[k]] = h_faces[3 * i + k];
     return TA_OK;
 }
 

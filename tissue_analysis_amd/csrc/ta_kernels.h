@@ -47,9 +47,14 @@ hipError_t launch_wall_group_by_pair(hipStream_t s, const uint32_t* pairs, const
                                      uint64_t* keys1, uint32_t* index0, uint32_t* index1, void* temp, uint64_t temp_bytes,
                                      int key_bits_lo, uint32_t* pairs_out, int32_t* coords_out);
 
-uint64_t pairs_sort_temp_bytes(uint64_t n);
-hipError_t launch_pairs_sort(hipStream_t s, uint64_t* keys0, uint64_t* keys1, uint32_t* index0, uint32_t* index1, const uint64_t* faces,
-                             uint64_t n, void* temp, uint64_t temp_bytes, uint64_t** keys_sorted, uint64_t* faces_out);
+// kernels_walls.hip (continued): exclusive scan of uint32 counts into uint64 offsets (three small kernels)
+uint64_t scan_u32_scratch_bytes(uint64_t n);
+void launch_scan_u32_exclusive(hipStream_t s, const uint32_t* counts, uint64_t n, void* scratch, uint64_t* offsets);
+
+// kernels_pairsort.hip -- the unique pairs sorted by (lo, hi): counting sort over the label rows + rank inside a bucket
+uint64_t pairs_sort_scratch_bytes(uint64_t n, uint32_t max_label);
+hipError_t launch_pairs_sort(hipStream_t s, const uint64_t* keys, const uint64_t* faces, uint64_t n, uint32_t max_label, void* scratch,
+                             uint64_t* keys_out, uint64_t* faces_out, const void* vol, int itemsize, int64_t corner);
 
 // kernels_basic.hip (continued)
 void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3], int64_t a_begin,
