@@ -47,3 +47,19 @@ def test_array_mode_gives_the_same_numbers():
     nei = arrays.neighbors()
     assert len(nei) == len(by_dict.neighbors())                       # (keys by position under NPLIST, SIA:642-645)
     assert nei.indptr[-1] == nei.indices.size and nei[2] == by_dict.extraction.neighbors_of(2)
+
+
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint32])
+def test_closed_form_volumes_boxes_barycentres_neighbours_and_walls_through_the_sweep(dtype):
+    """The box tiled by 27 staggered cuboids (tests/analytic_shapes.py): every per-label and per-pair answer of the class,
+    from the HIP sweep, against closed forms -- and the sweep's integer arrays against the closed-form face counts."""
+    import analytic_shapes
+    vol, cells = analytic_shapes.build(dtype)
+    sia = SpatialImageAnalysis(SpatialImage(vol, voxelsize=analytic_shapes.VOXELSIZE), ignoredlabels=0, return_type=DICT,
+                               background=1)
+    analytic_shapes.check(sia, cells)
+    want = analytic_shapes.expected(cells)
+    x = sia.extraction
+    got = dict(zip(zip(x.pair_lo.tolist(), x.pair_hi.tolist()), x.pair_faces.tolist()))
+    assert sorted(got) == sorted(want["faces"])
+    assert all(got[k] == f.tolist() for k, f in want["faces"].items())
