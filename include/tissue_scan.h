@@ -211,12 +211,15 @@ TA_API int ta_volume_first_layer(ta_ctx* ctx, uint32_t background, int keep_back
  * A voxel p of label l is a wall voxel of the pair (l, m) when one of its 18 neighbours (faces and
  * edges: scipy generate_binary_structure(3, 2), SIA:796-799) carries a label m != l; this is
  * (dil(mask_l) & mask_m) | (dil(mask_m) & mask_l) of wall_voxels_between_two_cells (SIA:759-806)
- * for every pair at once.  ta_wall_voxels_count runs the counting pass (one count per row strip, scanned
- * on the device: the host reads back one number) and returns the number of (pair, voxel) records;
- * ta_wall_voxels_get runs the emit pass and fills caller-allocated arrays of that length: the labels
+ * for every pair at once.  ta_wall_voxels_count runs the one compute pass -- it finds every record and keeps it in a
+ * staging area on the device (about 6 bytes per voxel of the volume, held until the volume changes), counts per row
+ * strip, scanned on the device: the host reads back one line -- and returns the number of (pair, voxel) records;
+ * ta_wall_voxels_get moves them into place and fills caller-allocated arrays of that length: the labels
  * pairs[r] = (lo, hi), lo < hi, and the voxel's coordinates in ARRAY-axis order, records ordered by the
- * voxel's position in memory (for a C-ordered array: np.where order).  ms (optional) receives the
- * duration of the kernels of both calls.  Not available on a slab with a halo plane. */
+ * voxel's position in memory (for a C-ordered array: np.where order; the records of one voxel in no particular
+ * order).  ms (optional) receives the duration of the kernels of both calls.  Not available on a slab with a halo
+ * plane.  Environment: TA_WALL_STAGE_RECORDS=<n> sizes the staging area (0: none, every strip is recomputed by the
+ * fetch -- the fallback noise volumes take anyway), TA_WALL_VERBOSE=1 prints one line per count. */
 TA_API int ta_wall_voxels_count(ta_ctx* ctx, int64_t* nrecords);
 TA_API int ta_wall_voxels_get(ta_ctx* ctx, uint32_t* pairs /* [n][2] */, int32_t* coords /* [n][3] */, double* ms);
 /* The same records GROUPED BY PAIR: sorted by (lo, hi) on the device (stable radix sort), the voxels of one pair still

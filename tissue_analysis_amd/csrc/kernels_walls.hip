@@ -5,21 +5,31 @@
 // {lo, hi, coordinates of p} per distinct m, records ordered by the position of p in memory.
 //
 // Layout of the work.  A wave walks DOWN axis 1 over `rows_per_wave` rows of one plane, for one strip of 256 columns:
-// lane i holds the four columns c0 + 4 i .. + 3 of the 3 x 3 rows around the current one in registers (one 8- or
-// 16-byte load per row and lane), so one step loads only the three new rows (one per plane) -- every row is read three
-// times in all, by the walkers of its own plane and of the two planes next to it, from L2 -- three of the four column
-// neighbours are the lane's own registers and the fourth comes from the next lane through DPP.
-// Out-of-volume neighbours are handled by CLAMPING the plane / row / column index: the clamped position is itself one
-// of the 18 neighbours (or the voxel), so it adds no label.
-// Distinct labels per voxel without an 18 x 18 compare: with x_q = neighbour_q XOR l, the distinct non-zero x are
-// pulled out in increasing order, one per round, by "smallest x above the last one" (18 subtracts + a min3 tree); a
-// round runs only while some lane of the wave still has one left (most steps: one or two rounds, none at all where
-// the 3 x 3 x 3 block is one label).
-// Two passes over the same decomposition: COUNT writes one record count per (row, strip) and one byte per lane of it;
-// an exclusive scan ON THE DEVICE turns the former into offsets; EMIT starts each lane at the strip's offset plus the
-// lanes before it, so the records come out in memory order with no atomics and without a second walk over the columns
-// (a column's labels are stored as soon as its rounds are done), already as (lo, hi) / coordinates in array-axis order.  The host reads back ONE number (the total)
-// between the passes, to size the output.
+// lane i holds the four columns c0 + 4 i .. + 3 of the 3 x 3 rows around the current one in registers -- a ring of three
+// row slots per plane, so nothing is moved; a step loads the three rows the next one will need (one 8- or 16-byte load
+// per row and lane) and leaves them as memory returned them until then -- every row is read three times in all, by the walkers of its own plane and of
+// the two planes next to it, from L2; three of the four column neighbours are the lane's own registers and the fourth
+// comes from the next lane through DPP.  Out-of-volume neighbours are handled by CLAMPING the plane / row / column
+// index: the clamped position is itself one of the 18 neighbours (or the voxel), so it adds no label.
+// A (row, strip) of the walk is a CELL: 256 voxels whose records are consecutive in the output.
+//
+// Distinct labels per voxel without an 18 x 18 compare: with t_q = (neighbour_q XOR l) - 1 (one v_xad_u32; a neighbour
+// of the voxel's own label wraps to 0xFFFFFFFF), the smallest t is the first label (unsigned min3 tree) and the largest
+// one is the last (SIGNED max3 tree: the wrapped ones are -1; labels from 2^31 up take the unsigned route, see WIDE):
+// 36 instructions per voxel, and the voxel is done where the two agree -- one neighbour label, most wall voxels.
+// Further labels come out in increasing order, one per round, by "smallest t above the last one" (18 subtracts + a
+// min3 tree); a round runs only while some lane of the wave still has one left.
+//
+// ONE compute pass.  COUNT finds the labels of a cell, takes room for its records in a STAGING area (a wave takes 512
+// records at a time with one returning atomic on one of 256 cursors that each own a region: no hot word, an atomic
+// every eighth cell or so) and stores them there as {label, the other label, column}
+// in memory order (lane, column, label); it leaves the cell's record count and its place in the staging area.  An
+// exclusive scan ON THE DEVICE turns the counts into offsets; the host reads back ONE line (total, cells not staged,
+// wide labels seen) to size the output; COPY moves every cell's records from the staging area to its offset, adding
+// the coordinates in array-axis order -- no atomics, no second look at the volume.  A cell whose records did not fit
+// its region, or that holds a voxel with more than three neighbour labels, is NOT staged but listed: EMIT, the same
+// code with one listed cell per wave, recomputes exactly those cells and stores their records where they belong (a few
+// cells around points where five cells meet; noise volumes; a staging area sized for tissue, half a record per voxel).
 #include "ta_kernels.h"
 #include "ta_sweep_common.h"
 
@@ -29,11 +39,10 @@ namespace {
 
 constexpr int WNJ = 4;                 // columns per lane
 constexpr int WSC = 64 * WNJ;          // columns per strip
+constexpr int WRING = 3;               // row slots per plane: above, current, below
+constexpr uint32_t WALL_NONE = 0xFFFFFFFFu;
 
-struct WallRow {                       // one row of the 3 x 3 window: 4 columns per lane + the two columns beside the strip
-    uint32_t v[WNJ];
-    uint32_t hl, hr;
-};
+struct WallQuad { uint32_t v[WNJ]; };
 
 __device__ __forceinline__ uint32_t lane_shl1(uint32_t src, uint32_t lane63_value) {
     // lane i <- src of lane i+1 ; lane 63 keeps lane63_value   (DPP wave_shl:1)
@@ -42,6 +51,7 @@ __device__ __forceinline__ uint32_t lane_shl1(uint32_t src, uint32_t lane63_valu
 
 __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(min(a, b), c); }
 __device__ __forceinline__ uint32_t umax3(uint32_t a, uint32_t b, uint32_t c) { return max(max(a, b), c); }
+__device__ __forceinline__ int32_t smax3(uint32_t a, uint32_t b, uint32_t c) { return max(max((int32_t)a, (int32_t)b), (int32_t)c); }
 
 // inclusive add-scan over the 64 lanes (row_shr 1,2,4,8 then the two row broadcasts)
 __device__ __forceinline__ uint32_t wall_scan_add(uint32_t x) {
@@ -53,84 +63,115 @@ __device__ __forceinline__ uint32_t wall_scan_add(uint32_t x) {
     return x;
 }
 
-// One row of the window: lane i takes the 4 consecutive columns c0 + 4 i .. + 3 -- ONE 8- or 16-byte load where the rows
-// are aligned for it -- clamped to the last column of the row; hl / hr: the columns beside the strip (scalar loads).
-template <typename T>
-__device__ __forceinline__ void wall_load_row(WallRow& r, const T* row, uint32_t colq, uint32_t last, bool quad_ok,
-                                              uint32_t col_left, uint32_t col_right) {
-    if (quad_ok) {
+// One row of the window: lane i takes the 4 consecutive columns colq .. + 3 -- ONE 8- or 16-byte load where rows are
+// aligned for it (QUADS: a lane is then wholly inside the row or wholly past its end, and a lane past the end reads the
+// row's last quad and keeps its last voxel four times) -- clamped to the last column of the row.  In two halves: the
+// LOAD leaves what memory returned in WallRaw, untouched, so that nothing waits for it; SETTLE, one step later, makes
+// the four labels of it.
+struct WallRaw { uint32_t r[WNJ]; };
+
+template <typename T, bool QUADS>
+__device__ __forceinline__ void wall_load_raw(WallRaw& n, const T* row, uint32_t colq, uint32_t last) {
+    if (QUADS) {
+        const uint32_t cl = colq <= last ? colq : last - (WNJ - 1);
         if (sizeof(T) == 4) {
-            const uint4 q = *reinterpret_cast<const uint4*>(row + colq);
-            r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
+            const uint4 q = *reinterpret_cast<const uint4*>(row + cl);
+            n.r[0] = q.x; n.r[1] = q.y; n.r[2] = q.z; n.r[3] = q.w;
         } else {
-            const uint2 q = *reinterpret_cast<const uint2*>(row + colq);
-            r.v[0] = q.x & 0xffffu; r.v[1] = q.x >> 16; r.v[2] = q.y & 0xffffu; r.v[3] = q.y >> 16;
+            const uint2 q = *reinterpret_cast<const uint2*>(row + cl);
+            n.r[0] = q.x; n.r[1] = q.y;
         }
     } else {
 #pragma unroll
         for (int j = 0; j < WNJ; ++j) {
             const uint32_t c = colq + (uint32_t)j;
-            r.v[j] = (uint32_t)row[c <= last ? c : last];
+            n.r[j] = (uint32_t)row[c <= last ? c : last];
         }
     }
-    r.hl = load_uniform_voxel<T>(row + col_left);
-    r.hr = load_uniform_voxel<T>(row + col_right);
 }
 
-// x_q = neighbour_q XOR v for the 18 neighbours of column j of the lane: the row itself and its four face rows
-// (side[0..4]) with their column neighbours, the four edge rows at the same column
-__device__ __forceinline__ void wall_neighbours(uint32_t (&x)[18], const WallRow* const (&side)[5], const uint32_t (&Lc)[5],
-                                                const uint32_t (&Rc)[5], const WallRow& e0, const WallRow& e1,
-                                                const WallRow& e2, const WallRow& e3, const int j, const uint32_t v) {
-    int q = 0;
+template <typename T, bool QUADS>
+__device__ __forceinline__ void wall_settle(WallQuad& q, const WallRaw& n, bool partial, bool past) {
+    if (QUADS && sizeof(T) == 2) {
+        q.v[0] = n.r[0] & 0xffffu; q.v[1] = n.r[0] >> 16; q.v[2] = n.r[1] & 0xffffu; q.v[3] = n.r[1] >> 16;
+    } else {
 #pragma unroll
-    for (int f = 0; f < 5; ++f) {
-        x[q++] = (j > 0 ? side[f]->v[j > 0 ? j - 1 : 0] : Lc[f]) ^ v;
-        if (f > 0) x[q++] = side[f]->v[j] ^ v;
-        x[q++] = (j < WNJ - 1 ? side[f]->v[j < WNJ - 1 ? j + 1 : j] : Rc[f]) ^ v;
+        for (int j = 0; j < WNJ; ++j) q.v[j] = n.r[j];
     }
-    x[q++] = e0.v[j] ^ v; x[q++] = e1.v[j] ^ v; x[q++] = e2.v[j] ^ v; x[q++] = e3.v[j] ^ v;
+    if (QUADS && partial) {
+        q.v[0] = past ? q.v[3] : q.v[0]; q.v[1] = past ? q.v[3] : q.v[1]; q.v[2] = past ? q.v[3] : q.v[2];
+    }
 }
 
-// the smallest x above d: d + 1 + min_q((x_q - d - 1) mod 2^32) -- an x at or below d wraps to the top, above every x
+// the smallest t above d: d + 1 + min_q((t_q - d - 1) mod 2^32) -- a t at or below d wraps to the top, above every t
 // that does not -- 18 subtracts and a min3 tree, no compares
-__device__ __forceinline__ uint32_t wall_next_above(const uint32_t (&x)[18], uint32_t d) {
+__device__ __forceinline__ uint32_t wall_next_above(const uint32_t (&t)[18], uint32_t d) {
     const uint32_t e = d + 1u;
-    uint32_t m = umin3(umin3(x[0] - e, x[1] - e, x[2] - e), umin3(x[3] - e, x[4] - e, x[5] - e),
-                       umin3(x[6] - e, x[7] - e, x[8] - e));
-    m = umin3(m, umin3(x[9] - e, x[10] - e, x[11] - e), umin3(x[12] - e, x[13] - e, x[14] - e));
-    m = umin3(m, x[15] - e, umin3(x[16] - e, x[17] - e, 0xFFFFFFFFu));
+    uint32_t m = umin3(umin3(t[0] - e, t[1] - e, t[2] - e), umin3(t[3] - e, t[4] - e, t[5] - e),
+                       umin3(t[6] - e, t[7] - e, t[8] - e));
+    m = umin3(m, umin3(t[9] - e, t[10] - e, t[11] - e), umin3(t[12] - e, t[13] - e, t[14] - e));
+    m = umin3(m, t[15] - e, umin3(t[16] - e, t[17] - e, 0xFFFFFFFFu));
     return m + e;
 }
 
 }  // namespace
 
+// a record in the staging area, as COUNT holds it: the voxel's label, t = (the other label XOR it) - 1, its column in the
+// cell's strip; COPY, where every lane has a record, makes (lo, hi) of it
+struct WallStaged { uint32_t own, t, column; };
+
 struct WallArgs {
     const void* vol;
     int64_t n0, n1, n2;
     int32_t nstrips, rows_per_wave;
-    int32_t quads_ok;              // rows start 4-element aligned and hold a multiple of 4 columns: one vector load per lane
-    uint32_t* counts;              // [n0 * n1 * nstrips] records of each (row, strip): written by COUNT, read by EMIT
-    uint8_t* lane_counts;          // [cells][64] records of each lane of each non-empty (row, strip): likewise
-    const uint64_t* offsets;       // EMIT: their exclusive scan
+    uint32_t* counts;              // [cells] records of each cell: written by COUNT
+    uint32_t* cell_base;           // [cells] first staged record of the cell, WALL_NONE = not staged: written by COUNT
+    uint8_t* lane_counts;          // [cells][64] records of each lane, cells that are not staged only
+    const uint64_t* offsets;       // COPY / EMIT: exclusive scan of counts
+    WallStaged* stage;             // [WALL_CURSORS * region]
+    uint32_t* cursors;             // [WALL_CURSORS][32] (one 128-byte line each): records taken from each region
+    uint32_t region;               // records per region
+    uint32_t* status;              // [0] cells not staged  [1] a label >= 2^31 was seen by a kernel that cannot take it
+    uint32_t* todo;                // [cells] the cells that are not staged, in no order: written by COUNT, EMIT takes one per wave
+    uint32_t ntodo;                // EMIT: how many
     uint2* out_pairs;              // [n] (lo, hi)
     int32_t* out_coords;           // [n][3], array-axis order
     int32_t inv[3];                // inv[i] = memory axis of array axis i
 };
 
-template <typename T, bool EMIT>
-__global__ void __launch_bounds__(256) wall_rows_kernel(WallArgs A) {
+constexpr int WALL_CURSORS = 256;
+constexpr uint32_t WALL_COPY_CELLS = 16;
+constexpr uint32_t WALL_PIECE = 512;   // records a wave takes from its region at a time (a cell of tissue holds ~60)
+
+// T: voxel type.  QUADS: rows start 4-element aligned and hold a multiple of 4 columns.  WIDE: labels may reach 2^31
+// (the signed max is replaced by XOR + unsigned max: 54 instructions per voxel instead of 36).  EMIT: the second walk.
+template <typename T, bool QUADS, bool WIDE, bool EMIT>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) wall_cells_kernel(WallArgs A) {
     const int lane = threadIdx.x & 63;
     const int64_t wi = (int64_t)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t chunks_b = (A.n1 + A.rows_per_wave - 1) / A.rows_per_wave;
-    const int64_t per_plane = chunks_b * A.nstrips;
-    if (wi >= A.n0 * per_plane) return;
-    const int64_t a = wi / per_plane, rem = wi - a * per_plane, cb = rem / A.nstrips;
-    const int32_t s = (int32_t)(rem - cb * A.nstrips);
-    const int64_t b0 = cb * A.rows_per_wave, b1 = b0 + A.rows_per_wave < A.n1 ? b0 + A.rows_per_wave : A.n1;
+    int64_t a, b0, b1;
+    int32_t s;
+    if (EMIT) {                        // one listed cell per wave
+        if (wi >= (int64_t)A.ntodo) return;
+        const uint32_t listed = (uint32_t)__builtin_amdgcn_readfirstlane((int)A.todo[wi]);
+        const uint32_t row = listed / (uint32_t)A.nstrips;
+        s = (int32_t)(listed - row * (uint32_t)A.nstrips);
+        a = (int64_t)(row / (uint32_t)A.n1);
+        b0 = (int64_t)row - a * A.n1;
+        b1 = b0 + 1;
+    } else {                           // rows_per_wave cells, down axis 1
+        const int64_t chunks_b = (A.n1 + A.rows_per_wave - 1) / A.rows_per_wave;
+        const int64_t per_plane = chunks_b * A.nstrips;
+        if (wi >= A.n0 * per_plane) return;
+        a = wi / per_plane;
+        const int64_t rem = wi - a * per_plane, cb = rem / A.nstrips;
+        s = (int32_t)(rem - cb * A.nstrips);
+        b0 = cb * A.rows_per_wave;
+        b1 = b0 + A.rows_per_wave < A.n1 ? b0 + A.rows_per_wave : A.n1;
+    }
     const uint32_t c0 = (uint32_t)s * WSC, last = (uint32_t)(A.n2 - 1);
     const uint32_t colq = c0 + (uint32_t)WNJ * (uint32_t)lane;
-    const bool quad_ok = A.quads_ok && colq + (WNJ - 1) <= last;
+    const bool partial = c0 + (uint32_t)(WSC - 1) > last;          // the strip reaches past the end of the rows
     const uint32_t col_left = c0 > 0u ? c0 - 1u : 0u, col_right = c0 + WSC <= last ? c0 + WSC : last;
     const T* vol = (const T*)A.vol;
     const T* plane[3];
@@ -144,129 +185,321 @@ __global__ void __launch_bounds__(256) wall_rows_kernel(WallArgs A) {
         b = b < 0 ? 0 : (b >= A.n1 ? A.n1 - 1 : b);
         return plane[p] + b * A.n2;
     };
-    const T* ahead[3];                 // row b + 2 of each plane, clamped: advanced by one row per step
-#pragma unroll
-    for (int p = 0; p < 3; ++p) ahead[p] = rowp(p, b0 + 1);
 
-    WallRow W[3][3], nxt[3];
+    // the window: W[p][k] = the lane's four columns of one row of plane p, a ring of three slots per plane (above, the row,
+    // below); H[p][k] = the two columns beside the strip, the left one in lanes 0 - 31 and the right one in lanes 32 - 63
+    // (one more small load per row: lane 0 / lane 63 is where the DPP shifts want them); U3 / R3[k] = "the three rows of
+    // slot k, those columns included, are all one label".  N / HN: the rows in flight -- loaded during one step, settled
+    // into the slot of the row that is no longer needed at the top of the next.
+    WallQuad W[3][WRING];
+    uint32_t H[3][WRING], R3[WRING];
+    bool U3[WRING];
+    WallRaw N[3];
+    uint32_t HN[3];
+    uint32_t seen = 0;                 // OR of every label loaded (WIDE detection)
+    const uint32_t hcol = lane < 32 ? col_left : col_right;
+    const bool lane_past = colq > last;
+    auto load_rows = [&](const T* const (&rows)[3], WallRaw (&n)[3], uint32_t (&hn)[3]) {
 #pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        wall_load_row<T>(W[p][1], rowp(p, b0 - 1), colq, last, quad_ok, col_left, col_right);
-        wall_load_row<T>(W[p][2], rowp(p, b0), colq, last, quad_ok, col_left, col_right);
-        wall_load_row<T>(nxt[p], ahead[p], colq, last, quad_ok, col_left, col_right);
+        for (int p = 0; p < 3; ++p) {
+            wall_load_raw<T, QUADS>(n[p], rows[p], colq, last);
+            hn[p] = (uint32_t)rows[p][hcol];
+        }
+    };
+    auto settle = [&](const WallRaw (&n)[3], const uint32_t (&hn)[3], const int k) {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            wall_settle<T, QUADS>(W[p][k], n[p], partial, lane_past);
+            H[p][k] = hn[p];
+        }
+        const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)W[1][k].v[0]);
+        uint32_t d = 0;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+            const WallQuad& q = W[p][k];
+            d |= ((q.v[0] ^ ref) | (q.v[1] ^ ref)) | ((q.v[2] ^ ref) | (q.v[3] ^ ref)) | (H[p][k] ^ ref);
+            if (sizeof(T) == 4 && !WIDE && !EMIT) seen |= (q.v[0] | q.v[1]) | (q.v[2] | q.v[3]);
+        }
+        R3[k] = ref;
+        U3[k] = !__any(d != 0u);
+    };
+    const T* ahead[3];                 // the row the next load takes, per plane
+    {
+        const T* r0[3] = {rowp(0, b0 - 1), rowp(1, b0 - 1), rowp(2, b0 - 1)};
+        const T* r1[3] = {rowp(0, b0), rowp(1, b0), rowp(2, b0)};
+        const T* r2[3] = {rowp(0, b0 + 1), rowp(1, b0 + 1), rowp(2, b0 + 1)};
+        WallRaw n0[3], n1[3];
+        uint32_t h0[3], h1[3];
+        load_rows(r0, n0, h0); load_rows(r1, n1, h1); load_rows(r2, N, HN);
+        settle(n0, h0, 0); settle(n1, h1, 1);
+#pragma unroll
+        for (int p = 0; p < 3; ++p) ahead[p] = r2[p];
     }
-    for (int64_t b = b0; b < b1; ++b) {
-#pragma unroll
-        for (int p = 0; p < 3; ++p) { W[p][0] = W[p][1]; W[p][1] = W[p][2]; W[p][2] = nxt[p]; }
+    const uint64_t cell0 = (uint64_t)((a * A.n1 + b0) * A.nstrips + s);
+    uint64_t cell = cell0;
+    const uint32_t region_of_wave = ((uint32_t)wi * 0x9E3779B1u) >> 24;          // 0 .. WALL_CURSORS - 1, scattered
+    // COUNT keeps what it finds in the wave's slice of LDS and in two registers (lane r: the cell of the wave's r-th row)
+    // and writes to memory when a piece is full and when the walk is over: a step then issues no store, and the wait for
+    // the rows it prefetched is not a wait for the stores before them (one counter for both, in issue order).
+    __shared__ uint32_t piece_lds[EMIT ? 1 : 4 * WALL_PIECE * 3];
+    uint32_t* const piece = piece_lds + (EMIT ? 0u : (threadIdx.x >> 6) * (WALL_PIECE * 3u));
+    uint32_t piece_at = 0, piece_used = 0, piece_size = 0;     // where the piece lies in the staging area, records in it, its size
+    uint32_t cell_counts = 0, cell_firsts = WALL_NONE;
+    auto flush_piece = [&]() {
+        for (uint32_t r = (uint32_t)lane; r < piece_used; r += 64u) {
+            WallStaged rec;
+            rec.own = piece[r]; rec.t = piece[WALL_PIECE + r]; rec.column = piece[2u * WALL_PIECE + r];
+            A.stage[piece_at + r] = rec;
+        }
+    };
+    const int32_t ma = (int32_t)a;
+    struct __attribute__((packed, aligned(4))) Int3 { int32_t x, y, z; };
+
+    // one step: the cell of row b; ring slots PH = above, PH + 1 = the row, PH + 2 = below
+    auto step = [&](auto ph, const int64_t b) {
+        constexpr int PH = decltype(ph)::value;
+        constexpr int KA = PH % WRING, KC = (PH + 1) % WRING, KB = (PH + 2) % WRING;
+        settle(N, HN, KB);                               // the rows loaded during the previous step: first use
         if (b + 1 < b1) {
             const int64_t adv = b + 2 < A.n1 ? A.n2 : 0;
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                ahead[p] += adv;
-                wall_load_row<T>(nxt[p], ahead[p], colq, last, quad_ok, col_left, col_right);
-            }
+            for (int p = 0; p < 3; ++p) ahead[p] += adv;
+            load_rows(ahead, N, HN);
         }
-        const int64_t cell = (a * A.n1 + b) * A.nstrips + s;
+        const uint64_t this_cell = cell;
+        cell += (uint64_t)A.nstrips;
         uint64_t base = 0;
         if (EMIT) {
-            if (A.counts[cell] == 0u) continue;         // the count pass found nothing here
-            base = A.offsets[cell];
-        }
-        // the whole 3 x 3 x (strip + 2) block one label: nothing to do (background, cell interiors)
-        {
-            const uint32_t ref = (uint32_t)__builtin_amdgcn_readfirstlane((int)W[1][1].v[0]);
-            uint32_t u = 0;
-#pragma unroll
-            for (int p = 0; p < 3; ++p)
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                    for (int j = 0; j < WNJ; ++j) u |= W[p][r].v[j] ^ ref;
-                    u |= (W[p][r].hl ^ ref) | (W[p][r].hr ^ ref);
-                }
-            if (!__any(u != 0u)) {
-                if (!EMIT && lane == 0) A.counts[cell] = 0u;
-                continue;
-            }
+            base = A.offsets[this_cell];
+        } else {
+            // the whole 3 x 3 x (strip + 2) block one label: nothing to do (background, cell interiors)
+            if (U3[KA] && U3[KC] && U3[KB] && R3[KA] == R3[KC] && R3[KB] == R3[KC]) return;
         }
         // the columns beside each lane's four, for the five rows whose column neighbours count (the row itself and its
-        // four face rows): from the next lane through DPP, from the scalar halo loads at the ends of the strip
-        const WallRow* const side[5] = {&W[1][1], &W[0][1], &W[2][1], &W[1][0], &W[1][2]};
+        // four face rows): from the next lane through DPP, at the ends of the strip what lane 0 / lane 63 of H hold
+        const WallQuad* const side[5] = {&W[1][KC], &W[0][KC], &W[2][KC], &W[1][KA], &W[1][KB]};
+        const uint32_t beside[5] = {H[1][KC], H[0][KC], H[2][KC], H[1][KA], H[1][KB]};
         uint32_t Lc[5], Rc[5];
 #pragma unroll
         for (int f = 0; f < 5; ++f) {
-            Lc[f] = lane_shr1(side[f]->v[WNJ - 1], side[f]->hl);
-            Rc[f] = lane_shl1(side[f]->v[0], side[f]->hr);
+            Lc[f] = lane_shr1(side[f]->v[WNJ - 1], beside[f]);
+            Rc[f] = lane_shl1(side[f]->v[0], beside[f]);
         }
-        // EMIT: where this lane's records go -- the row strip's offset plus the lanes before it (their totals were
-        // written by the count pass), so a column's labels are stored as soon as its rounds are done
-        uint32_t pos = 0;                       // relative to the strip's first record: 32-bit offsets from a scalar base
+        const WallQuad& e0 = W[0][KA]; const WallQuad& e1 = W[0][KB]; const WallQuad& e2 = W[2][KA]; const WallQuad& e3 = W[2][KB];
+        const bool past = partial && colq > last;         // QUADS: a lane is wholly in or wholly out
+
+        uint32_t pos = 0;                       // EMIT: relative to the cell's first record
         uint2* out_pairs = nullptr;
         int32_t* out_coords = nullptr;
         if (EMIT) {
-            const uint32_t mine = A.lane_counts[cell * 64 + lane];
+            const uint32_t mine = A.lane_counts[this_cell * 64 + lane];
             pos = wall_scan_add(mine) - mine;
             out_pairs = A.out_pairs + base;
             out_coords = A.out_coords + 3 * base;
         }
-        const int32_t ma = (int32_t)a, mb = (int32_t)b;
-        struct __attribute__((packed, aligned(4))) Int3 { int32_t x, y, z; };
+        uint32_t K[WNJ][3];                     // COUNT: the first three labels of each column, as t = (label XOR v) - 1
+        uint32_t nn = 0;                        // records of column j in byte j
+        bool many = false;                      // a voxel of this lane has more than three labels
         uint32_t total = 0;
 #pragma unroll
         for (int j = 0; j < WNJ; ++j) {
-            const uint32_t v = W[1][1].v[j];
-            uint32_t x[18];
-            wall_neighbours(x, side, Lc, Rc, W[0][0], W[0][2], W[2][0], W[2][2], j, v);
-            uint32_t mx = umax3(umax3(x[0], x[1], x[2]), umax3(x[3], x[4], x[5]), umax3(x[6], x[7], x[8]));
-            mx = umax3(mx, umax3(x[9], x[10], x[11]), umax3(x[12], x[13], x[14]));
-            mx = umax3(mx, umax3(x[15], x[16], x[17]), 0u);
-            if (colq + (uint32_t)j > last) mx = 0u;            // a column past the end of the row (clamped copies)
-            if (!__any(mx != 0u)) continue;
+            const uint32_t v = W[1][KC].v[j];
+            uint32_t t[18];
+            {
+                uint32_t nb[18];
+                int q = 0;
+#pragma unroll
+                for (int f = 0; f < 5; ++f) {
+                    nb[q++] = j > 0 ? side[f]->v[j > 0 ? j - 1 : 0] : Lc[f];
+                    if (f > 0) nb[q++] = side[f]->v[j];
+                    nb[q++] = j < WNJ - 1 ? side[f]->v[j < WNJ - 1 ? j + 1 : j] : Rc[f];
+                }
+                nb[q++] = e0.v[j]; nb[q++] = e1.v[j]; nb[q++] = e2.v[j]; nb[q++] = e3.v[j];
+#pragma unroll
+                for (int i = 0; i < 18; ++i) t[i] = (nb[i] ^ v) + 0xFFFFFFFFu;
+            }
+            uint32_t tmin = umin3(umin3(t[0], t[1], t[2]), umin3(t[3], t[4], t[5]), umin3(t[6], t[7], t[8]));
+            tmin = umin3(tmin, umin3(t[9], t[10], t[11]), umin3(t[12], t[13], t[14]));
+            tmin = umin3(tmin, t[15], umin3(t[16], t[17], 0xFFFFFFFFu));
+            uint32_t tmax;                       // the largest t of a neighbour with another label, WALL_NONE without one
+            if (!WIDE) {
+                int32_t m = smax3((uint32_t)smax3(t[0], t[1], t[2]), (uint32_t)smax3(t[3], t[4], t[5]), (uint32_t)smax3(t[6], t[7], t[8]));
+                m = smax3((uint32_t)m, (uint32_t)smax3(t[9], t[10], t[11]), (uint32_t)smax3(t[12], t[13], t[14]));
+                m = smax3((uint32_t)m, (uint32_t)smax3(t[15], t[16], t[17]), 0xFFFFFFFFu);
+                tmax = (uint32_t)m;
+            } else {
+                uint32_t m = umax3(umax3(t[0] + 1u, t[1] + 1u, t[2] + 1u), umax3(t[3] + 1u, t[4] + 1u, t[5] + 1u),
+                                   umax3(t[6] + 1u, t[7] + 1u, t[8] + 1u));
+                m = umax3(m, umax3(t[9] + 1u, t[10] + 1u, t[11] + 1u), umax3(t[12] + 1u, t[13] + 1u, t[14] + 1u));
+                m = umax3(m, umax3(t[15] + 1u, t[16] + 1u, t[17] + 1u), 0u);
+                tmax = m - 1u;
+            }
+            if (QUADS ? past : colq + (uint32_t)j > last) { tmin = WALL_NONE; tmax = WALL_NONE; }   // a column past the end of the row (clamped copies)
+            if (!EMIT) { K[j][0] = tmin; K[j][1] = 0u; K[j][2] = 0u; }
+            if (!__any(tmax != WALL_NONE)) continue;
             Int3 xyz;                                          // the voxel in array-axis order: one 12-byte store per record
             if (EMIT) {
-                const int32_t mc = (int32_t)(colq + (uint32_t)j);
+                const int32_t mb = (int32_t)b, mc = (int32_t)(colq + (uint32_t)j);
                 xyz.x = A.inv[0] == 0 ? ma : (A.inv[0] == 1 ? mb : mc);
                 xyz.y = A.inv[1] == 0 ? ma : (A.inv[1] == 1 ? mb : mc);
                 xyz.z = A.inv[2] == 0 ? ma : (A.inv[2] == 1 ? mb : mc);
             }
-            auto put = [&](uint32_t xd) {
-                const uint32_t m = v ^ xd;
+            auto put = [&](uint32_t td) {
+                const uint32_t m = v ^ (td + 1u);
                 out_pairs[pos] = make_uint2(v < m ? v : m, v < m ? m : v);
                 *reinterpret_cast<Int3*>(out_coords + 3u * pos) = xyz;
                 ++pos;
             };
-            // distinct x in increasing order, one per round.  The first round (d = 0) gives the smallest non-zero x;
-            // where it equals the largest there is one label and the voxel is done -- most wall voxels.  Further rounds
-            // run only while some lane of the wave still has labels between its last one and its largest.  EMIT keeps
-            // the first three labels in registers and stores them after the rounds (one pass of stores per column, not
-            // one per round); a fourth and later label -- rare -- is stored where it is found.
-            uint32_t d = mx ? wall_next_above(x, 0u) : 0u;
-            const uint32_t k0 = d;
-            uint32_t k1 = 0u, k2 = 0u, n = mx ? 1u : 0u;
-            if (__any(d < mx)) {
-                const uint32_t nd = wall_next_above(x, d);
-                if (d < mx) { d = nd; k1 = nd; ++n; }
-                if (__any(d < mx)) {
-                    const uint32_t nd2 = wall_next_above(x, d);
-                    if (d < mx) { d = nd2; k2 = nd2; ++n; }
+            // distinct t in increasing order, one per round.  The first one is tmin; where it equals the largest there is
+            // one label and the voxel is done -- most wall voxels.  Further rounds run only while some lane of the wave
+            // still has labels between its last one and its largest.  (Unsigned compares: a lane without any holds
+            // WALL_NONE in both.)
+            uint32_t d = tmin, n = tmax != WALL_NONE ? 1u : 0u;
+            if (EMIT && n) put(d);
+            if (__any(d < tmax)) {
+                const uint32_t nd = wall_next_above(t, d);
+                const bool more = d < tmax;
+                if (EMIT) { if (more) put(nd); } else K[j][1] = nd;          // (K: read only where n says so)
+                d = more ? nd : d; n += more ? 1u : 0u;
+                if (__any(d < tmax)) {
+                    const uint32_t nd2 = wall_next_above(t, d);
+                    const bool more2 = d < tmax;
+                    if (EMIT) { if (more2) put(nd2); } else K[j][2] = nd2;
+                    d = more2 ? nd2 : d; n += more2 ? 1u : 0u;
+                    while (__any(d < tmax)) {
+                        const uint32_t nd3 = wall_next_above(t, d);
+                        const bool more3 = d < tmax;
+                        if (EMIT) { if (more3) put(nd3); }
+                        d = more3 ? nd3 : d; n += more3 ? 1u : 0u; many = many || more3;
+                    }
                 }
             }
-            if (EMIT) {
-                if (n > 0u) put(k0);
-                if (n > 1u) put(k1);
-                if (n > 2u) put(k2);
-            }
-            while (__any(d < mx)) {
-                const uint32_t nd = wall_next_above(x, d);
-                if (d < mx) { d = nd; ++n; if (EMIT) put(nd); }
-            }
             total += n;
+            nn |= n << (8 * j);
         }
-        if (!EMIT) {
-            A.lane_counts[cell * 64 + lane] = (uint8_t)total;          // <= 4 x 18
-            const uint32_t incl = wall_scan_add(total);
-            if (lane == 63) A.counts[cell] = incl;
+        if (EMIT) return;
+        const uint32_t incl = wall_scan_add(total);
+        const uint32_t cell_total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+        if (cell_total == 0u) return;
+        // room in the staging area: in the piece this wave holds; a new piece (one returning atomic on this wave's cursor)
+        // when the cell does not fit what is left of it, the full one goes to memory first
+        uint32_t first = WALL_NONE;
+        if (!__any(many) && cell_total <= WALL_PIECE) {
+            if (cell_total > piece_size - piece_used) {
+                flush_piece();
+                piece_used = 0; piece_size = 0;
+                uint32_t got = 0;
+                if (lane == 0) got = __hip_atomic_fetch_add(A.cursors + region_of_wave * 32u, WALL_PIECE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+                if (got <= A.region && WALL_PIECE <= A.region - got) { piece_at = region_of_wave * A.region + got; piece_size = WALL_PIECE; }
+            }
+            if (cell_total <= piece_size - piece_used) first = piece_at + piece_used;
         }
+        const int rth = (int)(b - b0);
+        cell_counts = lane == rth ? cell_total : cell_counts;
+        cell_firsts = lane == rth ? first : cell_firsts;
+        if (first == WALL_NONE) {
+            A.lane_counts[this_cell * 64 + lane] = (uint8_t)total;          // <= 4 x 18
+            if (lane == 0) A.todo[atomicAdd(A.status, 1u)] = (uint32_t)this_cell;
+            return;
+        }
+        uint32_t at = piece_used + incl - total;
+        piece_used += cell_total;
+        const bool several = __any((nn & 0xFEFEFEFEu) != 0u);          // some voxel of the cell has more than one label
+        auto keep = [&](const uint32_t where, const uint32_t v, const uint32_t tk, const uint32_t column) {
+            piece[where] = v; piece[WALL_PIECE + where] = tk; piece[2u * WALL_PIECE + where] = column;    // (one address, three offsets)
+        };
+#pragma unroll
+        for (int j = 0; j < WNJ; ++j) {
+            const uint32_t v = W[1][KC].v[j], nj = (nn >> (8 * j)) & 0xffu, column = (uint32_t)(WNJ * lane + j);
+            if (nj > 0u) keep(at, v, K[j][0], column);
+            if (several) {
+#pragma unroll
+                for (int i = 1; i < 3; ++i) {
+                    if (!__any(nj > (uint32_t)i)) break;
+                    if (nj > (uint32_t)i) keep(at + (uint32_t)i, v, K[j][i], column);
+                }
+            }
+            at += nj;
+        }
+    };
+
+    for (int64_t b = b0; b < b1; b += WRING) {
+        step(std::integral_constant<int, 0>(), b);
+        if (b + 1 < b1) step(std::integral_constant<int, 1>(), b + 1);
+        if (b + 2 < b1) step(std::integral_constant<int, 2>(), b + 2);
+    }
+    if (!EMIT) {
+        flush_piece();
+        if ((int64_t)lane < b1 - b0) {
+            const uint64_t mine = cell0 + (uint64_t)lane * (uint64_t)A.nstrips;
+            A.counts[mine] = cell_counts;
+            A.cell_base[mine] = cell_firsts;
+        }
+        if (sizeof(T) == 4 && !WIDE) {
+            if (__any((int32_t)seen < 0) && lane == 0) A.status[1] = 1u;
+        }
+    }
+}
+
+// COPY: a wave takes 16 cells -- one per lane for the bookkeeping, then four cells at a time with all lanes on their records
+__global__ void __launch_bounds__(256) wall_copy_kernel(WallArgs A, uint32_t ncells) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t first_cell = (blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * WALL_COPY_CELLS;
+    if (first_cell >= ncells) return;
+    const uint32_t cell = first_cell + (uint32_t)lane;
+    uint32_t cnt = 0, from = WALL_NONE;
+    uint64_t to = 0;
+    if (lane < (int)WALL_COPY_CELLS && cell < ncells) { cnt = A.counts[cell]; from = A.cell_base[cell]; to = A.offsets[cell]; }
+    if (cnt == 0u || from == WALL_NONE) cnt = 0u;
+    const uint32_t row = cell / (uint32_t)A.nstrips, strip = cell - row * (uint32_t)A.nstrips;
+    const uint32_t pa = row / (uint32_t)A.n1, pb = row - pa * (uint32_t)A.n1;
+    struct __attribute__((packed, aligned(4))) Int3 { int32_t x, y, z; };
+    struct Cell { uint32_t n, src, c0; int32_t ma, mb; uint64_t dst; };
+    auto take = [&](const int L) {
+        Cell c;
+        c.n = (uint32_t)__builtin_amdgcn_readlane((int)cnt, L);
+        c.src = (uint32_t)__builtin_amdgcn_readlane((int)from, L);
+        c.dst = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(to >> 32), L) << 32) |
+                (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)to, L);
+        c.ma = __builtin_amdgcn_readlane((int)pa, L);
+        c.mb = __builtin_amdgcn_readlane((int)pb, L);
+        c.c0 = (uint32_t)__builtin_amdgcn_readlane((int)strip, L) * WSC;
+        return c;
+    };
+    auto put = [&](const Cell& c, const uint32_t r, const WallStaged& rec) {
+        const int32_t mc = (int32_t)(c.c0 + rec.column);
+        Int3 xyz;
+        xyz.x = A.inv[0] == 0 ? c.ma : (A.inv[0] == 1 ? c.mb : mc);
+        xyz.y = A.inv[1] == 0 ? c.ma : (A.inv[1] == 1 ? c.mb : mc);
+        xyz.z = A.inv[2] == 0 ? c.ma : (A.inv[2] == 1 ? c.mb : mc);
+        const uint32_t other = rec.own ^ (rec.t + 1u);
+        A.out_pairs[c.dst + r] = make_uint2(rec.own < other ? rec.own : other, rec.own < other ? other : rec.own);
+        *reinterpret_cast<Int3*>(A.out_coords + 3 * (c.dst + r)) = xyz;
+    };
+    uint64_t todo = __ballot(cnt != 0u);
+    while (todo) {
+        // four cells at a time: their loads are in flight together (a cell of tissue holds ~60 records: one per lane)
+        constexpr int DEPTH = 4;
+        Cell c[DEPTH];
+        WallStaged rec[DEPTH];
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u) {
+            c[u].n = 0u;
+            if (todo) {
+                c[u] = take(__builtin_ctzll(todo));
+                todo &= todo - 1;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u)
+            if ((uint32_t)lane < c[u].n) rec[u] = A.stage[c[u].src + (uint32_t)lane];
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u)
+            if ((uint32_t)lane < c[u].n) put(c[u], (uint32_t)lane, rec[u]);
+#pragma unroll
+        for (int u = 0; u < DEPTH; ++u)
+            for (uint32_t r = (uint32_t)lane + 64u; r < c[u].n; r += 64u) put(c[u], r, A.stage[c[u].src + r]);
     }
 }
 
@@ -353,7 +586,7 @@ void launch_scan_u32_exclusive(hipStream_t s, const uint32_t* counts, uint64_t n
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------
-static int wall_rows_per_wave(int64_t n1) { return n1 < 16 ? (int)(n1 > 0 ? n1 : 1) : 16; }
+static int wall_rows_per_wave(int64_t n1) { return n1 < 16 ? (int)(n1 > 0 ? n1 : 1) : 16; }     // (8, 32, 64 rows: slower on C2)
 
 WallPlan wall_plan(int64_t n0, int64_t n1, int64_t n2) {
     WallPlan p;
@@ -366,41 +599,55 @@ WallPlan wall_plan(int64_t n0, int64_t n1, int64_t n2) {
     return p;
 }
 
-static WallArgs wall_args(const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2, const WallPlan& p) {
+uint64_t wall_stage_bytes(uint64_t records_per_region) { return (uint64_t)WALL_CURSORS * records_per_region * sizeof(WallStaged); }
+uint64_t wall_cursor_bytes() { return (uint64_t)WALL_CURSORS * 128; }
+uint32_t wall_stage_regions() { return WALL_CURSORS; }
+
+static WallArgs wall_args(const void* vol, int64_t n0, int64_t n1, int64_t n2, const WallPlan& p, const WallBuffers& b) {
     WallArgs a;
     a.vol = vol; a.n0 = n0; a.n1 = n1; a.n2 = n2;
-    a.quads_ok = ((uintptr_t)vol % (uintptr_t)(WNJ * itemsize) == 0) && (n2 % WNJ == 0);
     a.nstrips = p.nstrips; a.rows_per_wave = p.rows_per_wave;
-    a.counts = nullptr; a.lane_counts = nullptr; a.offsets = nullptr; a.out_pairs = nullptr; a.out_coords = nullptr;
+    a.counts = b.counts; a.cell_base = b.cell_base; a.lane_counts = b.lane_counts; a.offsets = b.offsets;
+    a.stage = (WallStaged*)b.stage; a.cursors = b.cursors; a.region = b.stage ? b.region : 0u; a.status = b.status;
+    a.todo = b.todo; a.ntodo = 0;
+    a.out_pairs = nullptr; a.out_coords = nullptr;
     a.inv[0] = 0; a.inv[1] = 1; a.inv[2] = 2;
     return a;
 }
 
-void launch_wall_count(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2,
-                       uint32_t* counts, uint8_t* lane_counts, uint64_t* offsets, uint64_t* block_sums, uint64_t* total) {
-    const WallPlan p = wall_plan(n0, n1, n2);
-    if (p.cells == 0) { (void)hipMemsetAsync(total, 0, 8, s); return; }
-    WallArgs a = wall_args(vol, itemsize, n0, n1, n2, p);
-    a.counts = counts; a.lane_counts = lane_counts;
-    const unsigned blocks = (unsigned)((p.waves + 3) / 4);
-    if (itemsize == 2) hipLaunchKernelGGL((wall_rows_kernel<uint16_t, false>), dim3(blocks), dim3(256), 0, s, a);
-    else               hipLaunchKernelGGL((wall_rows_kernel<uint32_t, false>), dim3(blocks), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(wall_scan_sums_kernel, dim3((unsigned)p.scan_blocks), dim3(256), 0, s, counts, p.cells, block_sums);
-    hipLaunchKernelGGL(wall_scan_top_kernel, dim3(1), dim3(256), 0, s, block_sums, p.scan_blocks, total);
-    hipLaunchKernelGGL(wall_scan_apply_kernel, dim3((unsigned)p.scan_blocks), dim3(256), 0, s, counts, p.cells, block_sums, offsets);
+template <bool EMIT>
+static void launch_wall_cells(hipStream_t s, const WallArgs& a, int itemsize, bool wide, unsigned blocks) {
+    const bool quads = ((uintptr_t)a.vol % (uintptr_t)(WNJ * itemsize) == 0) && (a.n2 % WNJ == 0);
+#define TA_WALL_GO(T, Q, W) hipLaunchKernelGGL((wall_cells_kernel<T, Q, W, EMIT>), dim3(blocks), dim3(256), 0, s, a)
+    if (itemsize == 2) { if (quads) TA_WALL_GO(uint16_t, true, false); else TA_WALL_GO(uint16_t, false, false); }
+    else if (!wide)    { if (quads) TA_WALL_GO(uint32_t, true, false); else TA_WALL_GO(uint32_t, false, false); }
+    else               { if (quads) TA_WALL_GO(uint32_t, true, true);  else TA_WALL_GO(uint32_t, false, true); }
+#undef TA_WALL_GO
 }
 
-void launch_wall_emit(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2,
-                      const uint32_t* counts, const uint8_t* lane_counts, const uint64_t* offsets, uint32_t* out_pairs,
-                      int32_t* out_coords, const int perm[3]) {
+void launch_wall_count(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2, const WallBuffers& b,
+                       bool wide) {
+    const WallPlan p = wall_plan(n0, n1, n2);
+    (void)hipMemsetAsync(b.total, 0, 16, s);                   // total | status[2]
+    if (p.cells == 0) return;
+    (void)hipMemsetAsync(b.cursors, 0, wall_cursor_bytes(), s);
+    const WallArgs a = wall_args(vol, n0, n1, n2, p, b);
+    launch_wall_cells<false>(s, a, itemsize, wide, (unsigned)((p.waves + 3) / 4));
+    hipLaunchKernelGGL(wall_scan_sums_kernel, dim3((unsigned)p.scan_blocks), dim3(256), 0, s, b.counts, p.cells, b.block_sums);
+    hipLaunchKernelGGL(wall_scan_top_kernel, dim3(1), dim3(256), 0, s, b.block_sums, p.scan_blocks, b.total);
+    hipLaunchKernelGGL(wall_scan_apply_kernel, dim3((unsigned)p.scan_blocks), dim3(256), 0, s, b.counts, p.cells, b.block_sums, b.offsets);
+}
+
+void launch_wall_fetch(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2, const WallBuffers& b,
+                       bool wide, uint32_t not_staged, uint32_t* out_pairs, int32_t* out_coords, const int perm[3]) {
     const WallPlan p = wall_plan(n0, n1, n2);
     if (p.cells == 0) return;
-    WallArgs a = wall_args(vol, itemsize, n0, n1, n2, p);
-    a.counts = const_cast<uint32_t*>(counts); a.lane_counts = const_cast<uint8_t*>(lane_counts); a.offsets = offsets; a.out_pairs = (uint2*)out_pairs; a.out_coords = out_coords;
+    WallArgs a = wall_args(vol, n0, n1, n2, p, b);
+    a.out_pairs = (uint2*)out_pairs; a.out_coords = out_coords;
     for (int k = 0; k < 3; ++k) a.inv[perm[k]] = k;          // perm[k] = array axis of memory axis k
-    const unsigned blocks = (unsigned)((p.waves + 3) / 4);
-    if (itemsize == 2) hipLaunchKernelGGL((wall_rows_kernel<uint16_t, true>), dim3(blocks), dim3(256), 0, s, a);
-    else               hipLaunchKernelGGL((wall_rows_kernel<uint32_t, true>), dim3(blocks), dim3(256), 0, s, a);
+    if (a.region) hipLaunchKernelGGL(wall_copy_kernel, dim3((unsigned)((p.cells + 4 * WALL_COPY_CELLS - 1) / (4 * WALL_COPY_CELLS))), dim3(256), 0, s, a, (uint32_t)p.cells);
+    a.ntodo = not_staged;
+    if (not_staged) launch_wall_cells<true>(s, a, itemsize, wide, (not_staged + 3u) / 4u);
 }
 
 }  // namespace ta

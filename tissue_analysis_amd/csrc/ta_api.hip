@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <numeric>
@@ -101,7 +102,10 @@ struct ta_ctx {
     DevBuf hot_rows;                                    // [workgroups][16] private rows of the hot label
     DevBuf sort_buf;                                    // scratch of ta_adjacency_get's device sort (kept between calls)
     DevBuf wall_counts;                                 // wall voxels: per-chunk record counts, then offsets
+    DevBuf wall_stage;                                  // wall voxels: the records the count pass staged (kept until the volume changes)
     int64_t wall_records = -1;                          // result of the last ta_wall_voxels_count, -1 = none
+    uint32_t wall_region = 0, wall_not_staged = 0;      // records per staging region of that call (0 = nothing staged); cells left to the second walk
+    bool wall_wide = false;                             // that call met a label >= 2^31
     double wall_ms = 0.0;
     int pair_log2 = 0;                                  // current table log2 capacity
     int opt_pair_log2 = 0;
@@ -360,6 +364,7 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     c->small.release();
     c->hot_rows.release(); c->sort_buf.release(); c->h_pairs.release();
     c->wall_counts.release();
+    c->wall_stage.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ring) if (e) (void)hipEventDestroy(e);
@@ -480,6 +485,7 @@ TA_API int ta_volume_set(ta_ctx* c, const void* host_ptr, int itemsize, const in
     c->vol = c->owned_vol.p;
     c->auto_tile_shift = 0;
     c->wall_records = -1;
+    c->wall_stage.release();
     c->itemsize = itemsize;
     for (int k = 0; k < 3; ++k) { c->perm[k] = perm[k]; c->mdims[k] = dims[perm[k]]; }
     c->a_origin = 0;
@@ -501,6 +507,7 @@ TA_API int ta_volume_set_device(ta_ctx* c, const void* dev_ptr, int itemsize, co
     c->volume_slack = 0;
     c->auto_tile_shift = 0;
     c->wall_records = -1;
+    c->wall_stage.release();
     c->itemsize = itemsize;
     for (int k = 0; k < 3; ++k) { c->perm[k] = k; c->mdims[k] = buf_dims[k]; }
     c->a_origin = a0_origin;
@@ -592,19 +599,45 @@ TA_API int ta_volume_first_layer(ta_ctx* c, uint32_t background, int keep_backgr
 }
 
 namespace {
-// layout of ta_ctx::wall_counts: counts u32[cells] (padded to 8 bytes) | offsets u64[cells] | block sums u64[scan_blocks] | total u64
-// | lane counts u8[cells][64]
-struct WallBufs { uint32_t* counts; uint64_t* offsets; uint64_t* block_sums; uint64_t* total; uint8_t* lane_counts; uint64_t bytes; };
-WallBufs wall_bufs(void* base, const ta::WallPlan& p) {
-    WallBufs b;
+// layout of ta_ctx::wall_counts: counts u32[cells] | cell_base u32[cells] (each padded to 8 bytes) | offsets u64[cells] |
+// block sums u64[scan_blocks] | total u64 + status u32[2] (the 16 bytes the host reads back) | cursors | todo u32[cells] |
+// lane counts u8[cells][64]
+uint64_t wall_bufs(void* base, const ta::WallPlan& p, ta::WallBuffers& b) {
     const uint64_t counts_bytes = (p.cells * 4 + 7) & ~7ull;
-    b.counts = (uint32_t*)base;
-    b.offsets = (uint64_t*)((char*)base + counts_bytes);
-    b.block_sums = b.offsets + p.cells;
-    b.total = b.block_sums + p.scan_blocks;
-    b.lane_counts = (uint8_t*)(b.total + 1);
-    b.bytes = counts_bytes + (p.cells + p.scan_blocks + 1) * 8 + p.cells * 64;
-    return b;
+    char* at = (char*)base;
+    b.counts = (uint32_t*)at; at += counts_bytes;
+    b.cell_base = (uint32_t*)at; at += counts_bytes;
+    b.offsets = (uint64_t*)at; at += p.cells * 8;
+    b.block_sums = (uint64_t*)at; at += p.scan_blocks * 8;
+    b.total = (uint64_t*)at; b.status = (uint32_t*)(b.total + 1); at += 16;
+    b.cursors = (uint32_t*)at; at += ta::wall_cursor_bytes();
+    b.todo = (uint32_t*)at; at += counts_bytes;
+    b.lane_counts = (uint8_t*)at; at += p.cells * 64;
+    return (uint64_t)(at - (char*)base);
+}
+
+// Room for the records the count pass stages: half a record per voxel (tissue: 0.1 - 0.25), split into regions; a
+// volume with more takes the second walk for the cells that did not fit.  No memory for it: nothing is staged.
+void wall_stage(ta_ctx* c, const ta::WallPlan& p, ta::WallBuffers& b) {
+    const uint64_t nvox = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2];
+    uint64_t records = std::min<uint64_t>(std::max<uint64_t>(nvox / 2, 1u << 16), 1ull << 31);
+    if (const char* env = getenv("TA_WALL_STAGE_RECORDS")) records = std::strtoull(env, nullptr, 10);      // tests: force the second walk
+    const uint32_t regions = ta::wall_stage_regions();
+    b.region = (uint32_t)(records / regions);
+    b.stage = nullptr;
+    (void)p;
+    if (b.region == 0) return;
+    if (c->wall_stage.bytes < ta::wall_stage_bytes(b.region)) {
+        c->wall_stage.release();
+        if (hipMalloc(&c->wall_stage.p, ta::wall_stage_bytes(b.region)) != hipSuccess) {
+            (void)hipGetLastError();
+            c->wall_stage.p = nullptr;
+            b.region = 0;
+            return;
+        }
+        c->wall_stage.bytes = ta::wall_stage_bytes(b.region);
+    }
+    b.stage = c->wall_stage.p;
 }
 }  // namespace
 
@@ -615,29 +648,44 @@ TA_API int ta_wall_voxels_count(ta_ctx* c, int64_t* nrecords) {
     int rc = use_device(c);
     if (rc != TA_OK) return rc;
     const ta::WallPlan plan = ta::wall_plan(c->mdims[0], c->mdims[1], c->mdims[2]);
-    if ((rc = c->wall_counts.reserve(wall_bufs(nullptr, plan).bytes)) != TA_OK) return rc;
-    const WallBufs wb = wall_bufs(c->wall_counts.p, plan);
+    if (plan.cells >= (1ull << 32)) return fail(TA_EINVAL, "volume too large for the wall voxel pass (%llu row strips)", (unsigned long long)plan.cells);
+    ta::WallBuffers wb;
+    if ((rc = c->wall_counts.reserve(wall_bufs(nullptr, plan, wb))) != TA_OK) return rc;
+    (void)wall_bufs(c->wall_counts.p, plan, wb);
+    wall_stage(c, plan, wb);
+    c->wall_region = wb.region;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    uint64_t total = 0;
+    struct { uint64_t total; uint32_t not_staged, wide_seen; } line = {0, 0, 0};
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
-    if (e == hipSuccess) {
-        // count per (row, strip), scan on the device: the only thing the host needs before the emit pass is the total
-        ta::launch_wall_count(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], wb.counts, wb.lane_counts,
-                              wb.offsets, wb.block_sums, wb.total);
-        e = hipGetLastError();
+    float ms_all = 0.f;
+    bool wide = false;
+    for (int attempt = 0; attempt < 2 && e == hipSuccess; ++attempt) {
+        e = hipEventRecord(e0, c->stream);
+        if (e == hipSuccess) {
+            // count + stage per (row, strip), scan on the device: the only thing the host needs before the fetch is one line
+            ta::launch_wall_count(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], wb, wide);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&line, wb.total, 16, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        float ms = 0.f;
+        if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+        ms_all += ms;
+        if (!line.wide_seen || wide) break;
+        wide = true;                    // a label from 2^31 up: once more with the kernel that takes them
     }
-    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(&total, wb.total, 8, hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    float ms = 0.f;
-    if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
     if (e0) (void)hipEventDestroy(e0);
     if (e1) (void)hipEventDestroy(e1);
     if (e != hipSuccess) return fail(TA_EHIP, "wall voxel count: %s", hipGetErrorString(e));
-    c->wall_records = (int64_t)total;
-    c->wall_ms = ms;
+    c->wall_records = (int64_t)line.total;
+    c->wall_not_staged = line.not_staged;
+    c->wall_wide = wide;
+    c->wall_ms = ms_all;
+    if (getenv("TA_WALL_VERBOSE"))
+        fprintf(stderr, "[tissue_scan] wall voxels: %llu records in %llu cells of 256 voxels, %u cells not staged (regions of %u records), wide=%d, %.3f ms\n",
+                (unsigned long long)line.total, (unsigned long long)plan.cells, line.not_staged, wb.region, (int)wide, ms_all);
     *nrecords = c->wall_records;
     return TA_OK;
 }
@@ -654,7 +702,10 @@ int wall_voxels_fetch(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_ou
     if (!pairs || !coords) return fail(TA_EINVAL, "NULL output array");
     if (by_pair && n >= (1ull << 32)) return fail(TA_EINVAL, "too many records (%llu) for the grouped fetch", (unsigned long long)n);
     const ta::WallPlan plan = ta::wall_plan(c->mdims[0], c->mdims[1], c->mdims[2]);
-    const WallBufs wb = wall_bufs(c->wall_counts.p, plan);
+    ta::WallBuffers wb;
+    (void)wall_bufs(c->wall_counts.p, plan, wb);
+    wb.region = c->wall_region;
+    wb.stage = c->wall_region ? c->wall_stage.p : nullptr;
     // one allocation: records in memory order | (grouped fetch) the same again grouped, sort keys / indices x 2, sort temp
     const uint64_t temp_bytes = by_pair ? ta::wall_sort_temp_bytes(n) : 0;
     const uint64_t rec = n * 8, co = (n * 12 + 15) & ~15ull, ix = (n * 4 + 15) & ~15ull;
@@ -669,9 +720,9 @@ int wall_voxels_fetch(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_ou
     if (e == hipSuccess) e = hipEventCreate(&e1);
     if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
     if (e == hipSuccess) {
-        // records leave the kernel as (lo, hi) / coordinates in ARRAY-axis order: straight into the caller's arrays
-        ta::launch_wall_emit(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], wb.counts, wb.lane_counts,
-                             wb.offsets, dpa, dco, c->perm);
+        // records leave the kernels as (lo, hi) / coordinates in ARRAY-axis order: straight into the caller's arrays
+        ta::launch_wall_fetch(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], wb, c->wall_wide,
+                              c->wall_not_staged, dpa, dco, c->perm);
         e = hipGetLastError();
     }
     if (e == hipSuccess && by_pair) {

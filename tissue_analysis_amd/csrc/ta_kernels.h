@@ -32,14 +32,30 @@ void launch_read_probe(hipStream_t s, const void* p, uint64_t bytes, uint32_t* s
 void launch_first_layer(hipStream_t s, const void* vol, int itemsize, void* out, int64_t n0, int64_t n1, int64_t n2,
                         uint32_t background, int keep_background);
 
-// kernels_walls.hip -- wall voxels (count per (row, strip) + device scan, then emit in memory order)
+// kernels_walls.hip -- wall voxels: count + stage per (row, strip) cell, device scan, copy in memory order (+ a second walk for
+// the cells that were not staged)
 struct WallPlan { int32_t nstrips, rows_per_wave; uint64_t cells, scan_blocks, waves; };
 WallPlan wall_plan(int64_t n0, int64_t n1, int64_t n2);
-void launch_wall_count(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2,
-                       uint32_t* counts, uint8_t* lane_counts, uint64_t* offsets, uint64_t* block_sums, uint64_t* total);
-void launch_wall_emit(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2,
-                      const uint32_t* counts, const uint8_t* lane_counts, const uint64_t* offsets, uint32_t* out_pairs,
-                      int32_t* out_coords, const int perm[3]);
+struct WallBuffers {
+    uint32_t* counts;        // [cells]
+    uint32_t* cell_base;     // [cells]
+    uint8_t* lane_counts;    // [cells][64]
+    uint64_t* offsets;       // [cells]
+    uint64_t* block_sums;    // [scan_blocks]
+    uint64_t* total;         // total u64 | status u32[2] (cells not staged, wide label seen): the line the host reads back
+    uint32_t* status;        // = (uint32_t*)(total + 1)
+    void* stage;             // wall_stage_bytes(region) or NULL: nothing is staged, every cell takes the second walk
+    uint32_t* cursors;       // wall_cursor_bytes()
+    uint32_t* todo;          // [cells] the cells left to the second walk
+    uint32_t region;         // records per staging region
+};
+uint64_t wall_stage_bytes(uint64_t records_per_region);
+uint64_t wall_cursor_bytes();
+uint32_t wall_stage_regions();
+void launch_wall_count(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2, const WallBuffers& b,
+                       bool wide);
+void launch_wall_fetch(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2, const WallBuffers& b,
+                       bool wide, uint32_t not_staged, uint32_t* out_pairs, int32_t* out_coords, const int perm[3]);
 
 // kernels_wallsort.hip -- the records grouped by pair (stable radix sort by lo << 32 | hi, then a gather)
 uint64_t wall_sort_temp_bytes(uint64_t n);
