@@ -207,6 +207,20 @@ TA_API int ta_volume_map(ta_ctx* ctx, const void* lut, uint32_t lut_len, const v
  * image has the dtype and dense layout of the volume given to ta_volume_set.  Not available on a slab with a halo. */
 TA_API int ta_volume_first_layer(ta_ctx* ctx, uint32_t background, int keep_background, void* host_dst);
 
+/* ---- hollowed-out cells and voxel layers (SURVEY.md §2 component 3: hollow_out_cells SIA:74-95, cells_walls_coords
+ * SIA:883-905, cells_voxel_layer SIA:1399-1448) ------------------------------------------------------------------------
+ * ta_volume_hollow: out[p] = V[p] where the Laplacian of the labels at p -- the sum of the six face neighbours minus
+ * 6 V[p], modulo 2^label_bits (the integer type of the image the caller holds: 8, 16, 32 or 64; 0 = the volume's own
+ * 16 / 32), the edge voxel repeated outside the image: what scipy.ndimage.laplace gives on an integer image -- is not
+ * zero and, with remove_background, V[p] != background; 0 elsewhere.  The host image has the dtype and dense layout of the
+ * volume given to ta_volume_set.
+ * ta_volume_layer18: out[p] = 1 where one of the 18 neighbours of p (faces + edges, inside the image) carries another
+ * label, else 0: `mask - binary_erosion(mask, generate_binary_structure(3, 2))` of EVERY label at once, up to the voxels
+ * on the faces of the crop the erosion is taken in, which the caller adds.  One byte per voxel, same layout.
+ * Neither is available on a slab with a halo plane. */
+TA_API int ta_volume_hollow(ta_ctx* ctx, uint32_t background, int remove_background, int label_bits, void* host_dst);
+TA_API int ta_volume_layer18(ta_ctx* ctx, uint8_t* host_dst);
+
 /* ---- wall voxels ------------------------------------------------------------
  * A voxel p of label l is a wall voxel of the pair (l, m) when one of its 18 neighbours (faces and
  * edges: scipy generate_binary_structure(3, 2), SIA:796-799) carries a label m != l; this is

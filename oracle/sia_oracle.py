@@ -433,6 +433,48 @@ class OracleSIA(object):
         return tuple(slice(a, b) for a, b in zip(starts, stops))
 
 
+    def cells_walls_coords(self):  # SIA:883-905, as written: `self.background` is the bound method, not its value
+        image = hollow_out_cells(np.asarray(self.image), self.background)
+        x, y, z = np.where(image != 0)
+        return list(x), list(y), list(z)
+
+    def cells_voxel_layer(self, labels, region_boundingbox=False, single_frame=False):  # SIA:1399-1448, as written
+        if isinstance(labels, int):
+            labels = [labels]
+        if single_frame:
+            region_boundingbox = True
+        if not isinstance(region_boundingbox, bool):
+            if sum([isinstance(s, slice) for s in region_boundingbox]) == 3:
+                bbox = region_boundingbox
+            else:
+                return None
+        elif isinstance(region_boundingbox, bool) and region_boundingbox:
+            bbox = self.region_boundingbox(labels)
+        else:
+            bboxes = self.boundingbox(labels, real=False)
+        struct = nd.generate_binary_structure(3, 2)
+        image = np.asarray(self.image)
+        if single_frame:
+            vox_layer = np.zeros_like(image[bbox], dtype=int)
+        else:
+            vox_layer = {}
+        for clabel in labels:
+            if region_boundingbox:
+                bbox_im = image[bbox]
+            else:
+                bbox_im = image[bboxes[clabel]]
+            mask_bbox_im = (bbox_im == clabel)
+            eroded_mask_bbox_im = nd.binary_erosion(mask_bbox_im, structure=struct)
+            layer = mask_bbox_im ^ eroded_mask_bbox_im      # `mask - eroded` of two boolean arrays (old numpy)
+            if single_frame:
+                vox_layer += np.array(layer, dtype=int)
+            else:
+                vox_layer[clabel] = np.array(layer, dtype=int)
+        if len(labels) == 1:
+            return vox_layer[clabel]
+        else:
+            return vox_layer
+
     # -- wall voxels (SIA:759-880, 1049-1111), as written: crops, two masks, 18-connectivity dilations
     def wall_voxels_between_two_cells(self, label_1, label_2):  # SIA:759-806 (bbox given as the dict of boxes)
         b1, b2 = self.boundingbox(label_1), self.boundingbox(label_2)
@@ -555,6 +597,16 @@ class OracleSIA(object):
 
     def remove_stack_margin_labels_from_image(self, erase_value=0, voxel_distance_from_margin=5, verbose=False):
         self.remove_labels_from_image(self.labels_at_stack_margins(voxel_distance_from_margin), erase_value, verbose)
+
+
+def hollow_out_cells(image, background, remove_background=True):  # SIA:74-95, as written
+    b = nd.laplace(image)
+    mask = b != 0
+    m = image * mask
+    if remove_background:
+        mask = m != background
+        m = m * mask
+    return m
 
 
 def find_wall_median_voxel(array):

@@ -5,6 +5,7 @@
 The brute force: for each of the 18 offsets of scipy's generate_binary_structure(3, 2), every voxel whose neighbour at that
 offset carries another label gives a record (lo, hi, voxel); the distinct records, in memory order, are what
 ta_wall_voxels_get returns -- and, stably sorted by pair, what ta_wall_voxels_get_by_pair returns."""
+import os
 import sys
 import numpy as np
 
@@ -33,7 +34,13 @@ for it in range(n):
     dtype = [np.uint16, np.uint32][rng.integers(0, 2)]
     shape = (int(rng.integers(1, 20)), int(rng.integers(1, 40)), int(rng.choice([1, 2, 3, 4, 7, 8, 64, 130, 255, 256, 257, 300, 512, 516, 770])))
     nlab = int(rng.integers(1, 12))
-    ids = np.unique(rng.integers(0, 65536 if dtype == np.uint16 else 1 << 22, size=nlab)).astype(dtype)
+    top = 65536 if dtype == np.uint16 else [1 << 22, 1 << 32][rng.integers(0, 2)]          # uint32: half the volumes hold labels >= 2^31
+    ids = np.unique(rng.integers(0, top, size=nlab)).astype(dtype)
+    staged = [None, 0, 256 * 8, 256 * 64][rng.integers(0, 4)]          # the staging area: default / none / regions of 8 / of 64 records
+    if staged is None:
+        os.environ.pop("TA_WALL_STAGE_RECORDS", None)
+    else:
+        os.environ["TA_WALL_STAGE_RECORDS"] = str(staged)
     block = (int(rng.integers(1, 5)), int(rng.integers(1, 7)), int(rng.integers(1, 30)))
     coarse = [int(np.ceil(s / b)) for s, b in zip(shape, block)]
     v = ids[rng.integers(0, ids.size, size=coarse)]

@@ -49,6 +49,8 @@ def walk_c_abi():
         "ta_volume_get": (None, buf),
         "ta_volume_map": (None, buf, 4, buf, 4, buf),
         "ta_volume_first_layer": (None, 1, 1, buf),
+        "ta_volume_hollow": (None, 1, 1, 0, buf),
+        "ta_volume_layer18": (None, buf),
         "ta_wall_voxels_count": (None, ctypes.byref(i64)),
         "ta_wall_voxels_get": (None, buf, buf, ctypes.byref(dbl)),
         "ta_wall_voxels_get_by_pair": (None, buf, buf, ctypes.byref(dbl)),

@@ -73,6 +73,11 @@ def test_labels_from_two_to_the_31_up():
     wide[vol == 8] = 0
     check(wide)
     check(vol + np.uint32(0x7FFFFF00))              # differences stay small, labels straddle 2^31
+    rng = np.random.default_rng(77)                 # noise over the whole 32-bit range: voxels ALL of whose neighbours differ in
+    for shape in ((4, 6, 40), (3, 5, 300)):         # bit 31 (the first kernel's signed maximum is then none of them: it must
+        check(rng.integers(0, 1 << 32, size=shape, dtype=np.uint64).astype(np.uint32))      # still end, and hand over to WIDE)
+    two = rng.integers(0, 2, size=(5, 7, 64)).astype(np.uint32) * np.uint32(0x80000001) + np.uint32(5)
+    check(two)
 
 
 @pytest.mark.parametrize("shape", [(5, 9, 260), (3, 4, 516), (2, 18, 1028), (3, 35, 256), (4, 17, 252), (1, 16, 4), (2, 33, 259)])

@@ -28,7 +28,7 @@ SYMBOLS = (
     "ta_version", "ta_adjacency_scope", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_get_option", "ta_ctx_synchronize", "ta_volume_set",
     "ta_volume_set_device", "ta_volume_max_label", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
-    "ta_volume_first_layer", "ta_wall_voxels_count", "ta_wall_voxels_get", "ta_wall_voxels_get_by_pair",
+    "ta_volume_first_layer", "ta_volume_hollow", "ta_volume_layer18", "ta_wall_voxels_count", "ta_wall_voxels_get", "ta_wall_voxels_get_by_pair",
     "ta_extract", "ta_get_labels",
     "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_timing_series", "ta_read_probe", "ta_debug_counters", "ta_bind_accumulators",
     "ta_accumulators_device", "ta_accumulators_reduced", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge",
@@ -90,6 +90,8 @@ def load():
         "ta_volume_get": (ci, [vp, vp]),
         "ta_volume_map": (ci, [vp, vp, u32, vp, ci, vp]),
         "ta_volume_first_layer": (ci, [vp, u32, ci, vp]),
+        "ta_volume_hollow": (ci, [vp, u32, ci, ci, vp]),
+        "ta_volume_layer18": (ci, [vp, vp]),
         "ta_wall_voxels_count": (ci, [vp, P(i64)]),
         "ta_wall_voxels_get": (ci, [vp, vp, vp, P(ctypes.c_double)]),
         "ta_wall_voxels_get_by_pair": (ci, [vp, vp, vp, P(ctypes.c_double)]),
@@ -263,6 +265,26 @@ class Context(object):
             raise ValueError("first_layer needs a dense (possibly axis-permuted) volume")
         _check(self._lib.ta_volume_first_layer(self._h, int(background), int(bool(keep_background)),
                                                ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+    def hollow(self, background, remove_background, like, label_bits=0):
+        """hollow_out_cells of the resident volume (SIA:74-95): the labels where their integer Laplacian (modulo
+        2^label_bits, 0 = the volume's own width) is not zero (and, with remove_background, where they are not the
+        background), 0 elsewhere; shaped and laid out like `like`."""
+        out = np.empty_like(like)
+        if not _dense_permuted(out):
+            raise ValueError("hollow needs a dense (possibly axis-permuted) volume")
+        _check(self._lib.ta_volume_hollow(self._h, int(background) & 0xFFFFFFFF, int(bool(remove_background)), int(label_bits),
+                                          ctypes.c_void_p(out.ctypes.data)))
+        return out
+
+    def layer18(self, like):
+        """uint8 image, 1 where a voxel has one of its 18 neighbours in another label (cells_voxel_layer, SIA:1399-1448,
+        for every label at once); shaped and laid out like `like`."""
+        out = np.empty_like(like, dtype=np.uint8)
+        if not _dense_permuted(out):
+            raise ValueError("layer18 needs a dense (possibly axis-permuted) volume")
+        _check(self._lib.ta_volume_layer18(self._h, ctypes.c_void_p(out.ctypes.data)))
         return out
 
     def wall_voxels(self, by_pair=False):

@@ -587,6 +587,149 @@ void launch_first_layer(hipStream_t s, const void* vol, int itemsize, void* out,
                            (uint32_t*)out, n0, n1, n2, background, keep_background);
 }
 
+// ------------------------------------------------------------------------------------------
+// hollow_out_cells (SIA:74-95): `image * (laplace(image) != 0)`, then `* (that != background)`.  scipy's laplace keeps
+// the image's integer type: each axis' v[-1] - 2 v + v[+1] is cast to it and the three are added in it, i.e. the whole
+// is (sum of the six face neighbours - 6 v) modulo 2^(bits of that type), with the edge voxel repeated outside the image
+// (mode 'reflect').  A wall voxel whose neighbours happen to cancel (v - 1 on one side, v + 1 on the other) is NOT kept,
+// like in the reference.  Same layout of the work as first_layer_kernel.
+template <typename T>
+__global__ void __launch_bounds__(256) hollow_kernel(const T* __restrict__ vol, T* __restrict__ out, int64_t n0, int64_t n1,
+                                                     int64_t n2, uint32_t bg, int remove_bg, int drop_bits) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int64_t strips = (n2 + VEC - 1) / VEC, total = n0 * n1 * strips;
+    const bool vec_ok = (n2 % VEC) == 0 && ((reinterpret_cast<uintptr_t>(vol) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % strips, row = i / strips, b = row % n1, a = row / n1, c0 = s * VEC;
+        const T* r = vol + row * n2;
+        T v[VEC], up[VEC], dn[VEC], pv[VEC], nx[VEC];
+        auto load = [&](const T* rp, T (&d)[VEC]) {
+            if (vec_ok) {
+                *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(rp + c0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) d[j] = rp[c0 + j < n2 ? c0 + j : n2 - 1];
+            }
+        };
+        load(r, v);
+        load(b > 0 ? r - n2 : r, up); load(b + 1 < n1 ? r + n2 : r, dn);
+        load(a > 0 ? r - n1 * n2 : r, pv); load(a + 1 < n0 ? r + n1 * n2 : r, nx);
+        const T left = r[c0 > 0 ? c0 - 1 : 0], right = r[c0 + VEC < n2 ? c0 + VEC : n2 - 1];
+        T o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const uint32_t l = j > 0 ? (uint32_t)v[j > 0 ? j - 1 : 0] : (uint32_t)left;
+            const uint32_t rr = j + 1 < VEC ? (uint32_t)(c0 + j + 1 < n2 ? v[j + 1 < VEC ? j + 1 : 0] : v[j]) : (uint32_t)right;
+            // exact in 64 bits, then modulo 2^(64 - drop_bits): the width of the image the caller holds
+            const uint64_t sum = (uint64_t)up[j] + (uint64_t)dn[j] + (uint64_t)pv[j] + (uint64_t)nx[j] + l + rr - 6ull * (uint64_t)v[j];
+            const bool keep = (sum << drop_bits) != 0ull && !(remove_bg && (uint32_t)v[j] == bg);
+            o[j] = keep ? v[j] : (T)0;
+        }
+        if (vec_ok) {
+            *reinterpret_cast<uint4*>(out + row * n2 + c0) = *reinterpret_cast<const uint4*>(o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) if (c0 + j < n2) out[row * n2 + c0 + j] = o[j];
+        }
+    }
+}
+
+void launch_hollow(hipStream_t s, const void* vol, int itemsize, void* out, int64_t n0, int64_t n1, int64_t n2, uint32_t background,
+                   int remove_background, int label_bits) {
+    const int drop_bits = 64 - label_bits;
+    const int64_t strips = (n2 + 16 / itemsize - 1) / (16 / itemsize), total = n0 * n1 * strips;
+    if (total <= 0) return;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (itemsize == 2)
+        hipLaunchKernelGGL(hollow_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)vol, (uint16_t*)out, n0, n1,
+                           n2, background, remove_background, drop_bits);
+    else
+        hipLaunchKernelGGL(hollow_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t*)vol, (uint32_t*)out, n0, n1,
+                           n2, background, remove_background, drop_bits);
+}
+
+// ------------------------------------------------------------------------------------------
+// The voxel layer of every cell at once (cells_voxel_layer, SIA:1399-1448: `mask - binary_erosion(mask, 18-structure)`
+// per label and crop): out[p] = 1 when one of the 18 neighbours of p (faces + edges, inside the image) carries another
+// label, else 0.  The erosion of one label's mask inside a crop removes exactly these voxels plus the label's voxels on
+// the faces of the crop, which the host adds.  One lane = VEC consecutive voxels of a row; the 3 x 3 rows around it come
+// as 16-byte loads, clamped at the image faces (a clamped row repeats a neighbour or the row itself: no new label).
+template <typename T>
+__global__ void __launch_bounds__(256) layer18_kernel(const T* __restrict__ vol, uint8_t* __restrict__ out, int64_t n0, int64_t n1,
+                                                      int64_t n2) {
+    constexpr int VEC = 16 / sizeof(T);
+    const int64_t strips = (n2 + VEC - 1) / VEC, total = n0 * n1 * strips;
+    const bool vec_ok = (n2 % VEC) == 0 && (reinterpret_cast<uintptr_t>(vol) & 15) == 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t s = i % strips, row = i / strips, b = row % n1, a = row / n1, c0 = s * VEC;
+        const int64_t cl = c0 > 0 ? c0 - 1 : 0, cr = c0 + VEC < n2 ? c0 + VEC : n2 - 1;
+        T v[VEC];
+        uint32_t other[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) other[j] = 0;
+        auto rowp = [&](int da, int db) {
+            int64_t aa = a + da, bb = b + db;
+            aa = aa < 0 ? 0 : (aa >= n0 ? n0 - 1 : aa);
+            bb = bb < 0 ? 0 : (bb >= n1 ? n1 - 1 : bb);
+            return vol + (aa * n1 + bb) * n2;
+        };
+        auto load = [&](const T* rp, T (&d)[VEC]) {
+            if (vec_ok) {
+                *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(rp + c0);
+            } else {
+#pragma unroll
+                for (int j = 0; j < VEC; ++j) d[j] = rp[c0 + j < n2 ? c0 + j : n2 - 1];
+            }
+        };
+        load(rowp(0, 0), v);
+#pragma unroll
+        for (int da = -1; da <= 1; ++da)
+#pragma unroll
+            for (int db = -1; db <= 1; ++db) {
+                const bool face = da == 0 || db == 0;         // the row itself and its four face rows: column neighbours count
+                const T* rp = rowp(da, db);
+                T d[VEC];
+                load(rp, d);
+                if (face) {
+                    const T left = rp[cl], right = rp[cr];
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) {
+                        const T l = j > 0 ? d[j > 0 ? j - 1 : 0] : left;
+                        const T r = j + 1 < VEC ? (c0 + j + 1 < n2 ? d[j + 1 < VEC ? j + 1 : 0] : d[j]) : right;
+                        other[j] |= (uint32_t)(l ^ v[j]) | (uint32_t)(r ^ v[j]) | (uint32_t)(d[j] ^ v[j]);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) other[j] |= (uint32_t)(d[j] ^ v[j]);
+                }
+            }
+        uint8_t o[VEC];
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = other[j] ? 1 : 0;
+        uint8_t* op = out + row * n2 + c0;
+        if (vec_ok && VEC == 8) {
+            *reinterpret_cast<uint2*>(op) = *reinterpret_cast<const uint2*>(o);
+        } else if (vec_ok && VEC == 4) {
+            *reinterpret_cast<uint32_t*>(op) = *reinterpret_cast<const uint32_t*>(o);
+        } else {
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) if (c0 + j < n2) op[j] = o[j];
+        }
+    }
+}
+
+void launch_layer18(hipStream_t s, const void* vol, int itemsize, uint8_t* out, int64_t n0, int64_t n1, int64_t n2) {
+    const int64_t strips = (n2 + 16 / itemsize - 1) / (16 / itemsize), total = n0 * n1 * strips;
+    if (total <= 0) return;
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    if (itemsize == 2)
+        hipLaunchKernelGGL(layer18_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)vol, out, n0, n1, n2);
+    else
+        hipLaunchKernelGGL(layer18_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t*)vol, out, n0, n1, n2);
+}
+
 void launch_map(hipStream_t s, const void* vol, int itemsize, void* out, int out_itemsize, uint64_t n,
                 const void* lut, uint32_t lut_len, uint64_t fill) {
     if (n == 0) return;

@@ -366,7 +366,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                     const bool more2 = d < tmax;
                     if (EMIT) { if (more2) put(nd2); } else K[j][2] = nd2;
                     d = more2 ? nd2 : d; n += more2 ? 1u : 0u;
-                    while (__any(d < tmax)) {
+                    // (at most 18 labels: the bound also ends the walk of the kernel without WIDE over labels from 2^31 up,
+                    // whose signed maximum need not be one of the t -- its counts are thrown away, the host runs WIDE)
+                    for (int round = 3; round < 19 && __any(d < tmax); ++round) {
                         const uint32_t nd3 = wall_next_above(t, d);
                         const bool more3 = d < tmax;
                         if (EMIT) { if (more3) put(nd3); }

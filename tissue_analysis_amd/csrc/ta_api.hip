@@ -598,6 +598,44 @@ TA_API int ta_volume_first_layer(ta_ctx* c, uint32_t background, int keep_backgr
     return TA_OK;
 }
 
+TA_API int ta_volume_hollow(ta_ctx* c, uint32_t background, int remove_background, int label_bits, void* host_dst) {
+    if (!c || !host_dst) return fail(TA_EINVAL, "NULL argument");
+    if (label_bits == 0) label_bits = 8 * c->itemsize;
+    if (label_bits != 8 && label_bits != 16 && label_bits != 32 && label_bits != 64) return fail(TA_EINVAL, "label_bits must be 0, 8, 16, 32 or 64");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    if (c->first_owned) return fail(TA_EINVAL, "hollowed-out cells are not available on a slab that carries a halo plane");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t bytes = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2] * c->itemsize;
+    DevBuf dout;
+    if ((rc = dout.reserve(bytes)) != TA_OK) return rc;
+    ta::launch_hollow(c->stream, c->vol, c->itemsize, dout.p, c->mdims[0], c->mdims[1], c->mdims[2], background, remove_background ? 1 : 0, label_bits);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host_dst, dout.p, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dout.release();
+    if (e != hipSuccess) return fail(TA_EHIP, "hollowed-out cells: %s", hipGetErrorString(e));
+    return TA_OK;
+}
+
+TA_API int ta_volume_layer18(ta_ctx* c, uint8_t* host_dst) {
+    if (!c || !host_dst) return fail(TA_EINVAL, "NULL argument");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    if (c->first_owned) return fail(TA_EINVAL, "the voxel layers are not available on a slab that carries a halo plane");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t bytes = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2];
+    DevBuf dout;
+    if ((rc = dout.reserve(bytes)) != TA_OK) return rc;
+    ta::launch_layer18(c->stream, c->vol, c->itemsize, (uint8_t*)dout.p, c->mdims[0], c->mdims[1], c->mdims[2]);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(host_dst, dout.p, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    dout.release();
+    if (e != hipSuccess) return fail(TA_EHIP, "voxel layers: %s", hipGetErrorString(e));
+    return TA_OK;
+}
+
 namespace {
 // layout of ta_ctx::wall_counts: counts u32[cells] | cell_base u32[cells] (each padded to 8 bytes) | offsets u64[cells] |
 // block sums u64[scan_blocks] | total u64 + status u32[2] (the 16 bytes the host reads back) | cursors | todo u32[cells] |

@@ -32,6 +32,10 @@ void launch_read_probe(hipStream_t s, const void* p, uint64_t bytes, uint32_t* s
 void launch_first_layer(hipStream_t s, const void* vol, int itemsize, void* out, int64_t n0, int64_t n1, int64_t n2,
                         uint32_t background, int keep_background);
 
+void launch_hollow(hipStream_t s, const void* vol, int itemsize, void* out, int64_t n0, int64_t n1, int64_t n2, uint32_t background,
+                   int remove_background, int label_bits);
+void launch_layer18(hipStream_t s, const void* vol, int itemsize, uint8_t* out, int64_t n0, int64_t n1, int64_t n2);
+
 // kernels_walls.hip -- wall voxels: count + stage per (row, strip) cell, device scan, copy in memory order (+ a second walk for
 // the cells that were not staged)
 struct WallPlan { int32_t nstrips, rows_per_wave; uint64_t cells, scan_blocks, waves; };

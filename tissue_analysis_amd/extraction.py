@@ -393,6 +393,12 @@ class ResidentVolume(object):
     def first_layer(self, background, keep_background=True):
         return self.ctx.first_layer(background, keep_background, self.host)
 
+    def hollow(self, background, remove_background=True, label_bits=0):
+        return self.ctx.hollow(background, remove_background, self.host, label_bits)
+
+    def layer18(self):
+        return self.ctx.layer18(self.host)
+
 
 def extract_volume(array, features=_capi.F_ALL, device=0, context=None, max_label=None,
                    impl=None, tile_planes=None):

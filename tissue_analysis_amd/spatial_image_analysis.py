@@ -69,6 +69,45 @@ def return_list_of_vectors(tensor, by_row=True):
     return [tensor[:, v] for v in range(len(tensor))]
 
 
+def _removable_background(background, dtype):
+    """What `m != background` of SIA:90-92 removes: an integer the image's type can hold; anything else (None, a label
+    out of range, an object such as the bound method SIA:895 passes) compares unequal everywhere and removes nothing."""
+    if isinstance(background, (bool, np.bool_)) or not isinstance(background, _INT + (np.integer,)):
+        return None
+    info = np.iinfo(dtype)
+    return int(background) if info.min <= int(background) <= info.max and int(background) >= 0 else None
+
+
+def _hollow(resident, image, background, remove_background):
+    arr = np.asarray(image)
+    bg = _removable_background(background, arr.dtype) if remove_background else None
+    out = resident.hollow(0 if bg is None else bg, bg is not None, 8 * arr.dtype.itemsize)
+    if arr.ndim == 2:
+        out = out[:, :, 0]
+    out = out.astype(arr.dtype, copy=False)
+    voxelsize = getattr(image, "voxelsize", None)
+    return SpatialImage(out, voxelsize=voxelsize) if voxelsize is not None else out
+
+
+def hollow_out_cells(image, background, remove_background=True, verbose=True, device=0):
+    """SIA:74-95: the image with only the cell walls left -- `image * (laplace(image) != 0)`, then without the background.
+    The Laplacian is scipy's on an integer image: six face neighbours minus 6 v in the image's own integer type, the edge
+    voxel repeated outside; one stencil pass on the GPU (`ta_volume_hollow`).  A non-negative integer image is needed;
+    the sums wrap modulo 2^bits of its type -- what scipy does for unsigned types, and for signed ones as long as
+    v[-1] - 2 v + v[+1] stays in range (labels below 2^29 in an int32 image)."""
+    from .extraction import ResidentVolume
+    if verbose:
+        print("Hollowing out cells... ", end="")
+    resident = ResidentVolume(np.asarray(image), device=device)
+    try:
+        m = _hollow(resident, image, background, remove_background)
+    finally:
+        resident.close()
+    if verbose:
+        print("Done !!")
+    return m
+
+
 class AbstractSpatialImageAnalysis(object):
     """Same surface as SIA:206-1176 for the hot-path methods; results come from one `Extraction`."""
 
@@ -110,6 +149,7 @@ class AbstractSpatialImageAnalysis(object):
         self._device = device
         self._rv = None
         self._voxel_layer1 = None
+        self._voxel_layer18 = None
         self._x = extraction if extraction is not None else self._sweep()
         if background is not None:
             if not self._x.has(int(background)):
@@ -140,6 +180,7 @@ class AbstractSpatialImageAnalysis(object):
         self._center_of_mass = {}
         self._walls = None
         self._voxel_layer1 = None
+        self._voxel_layer18 = None
 
     @property
     def extraction(self):
@@ -450,6 +491,68 @@ class AbstractSpatialImageAnalysis(object):
                                               voxelsize=getattr(self.image, "voxelsize", None))
         return self._voxel_layer1
 
+    # -- coordinates of every voxel next to another label (SIA:883-905)
+    def cells_walls_coords(self):
+        """x, y, z (lists) of the voxels `hollow_out_cells` keeps.  As written in the reference: the background handed to
+        it is the bound method `self.background` (SIA:895), which no voxel equals, so background voxels next to a cell
+        are returned too; label 0 never is (`image * mask` is 0 there).  2-D images: every voxel that is not 0 (the same
+        comparison with the method leaves the background in, SIA:897-898)."""
+        if self.is3D():
+            image = np.asarray(_hollow(self._resident(), self.image, self.background, True))
+            x, y, z = np.where(image != 0)
+            return list(x), list(y), list(z)
+        x, y = np.where(np.asarray(self.image) != 0)
+        return list(x), list(y)
+
+    # -- the first layer of voxels of a cell (SIA:1399-1448): `mask - binary_erosion(mask, 18-structure)` inside a crop.
+    # A voxel of the cell is eroded away unless all its 18 neighbours are the cell's AND inside the crop, so the layer is
+    # the cell's voxels that have another label among their 18 neighbours -- one stencil pass over the resident volume
+    # for every label at once (`ta_volume_layer18`) -- plus the cell's voxels on the faces of the crop.
+    def _layer18(self):
+        if getattr(self, "_voxel_layer18", None) is None:
+            self._voxel_layer18 = self._resident().layer18()
+        return self._voxel_layer18
+
+    def cells_voxel_layer(self, labels, region_boundingbox=False, single_frame=False):
+        if isinstance(labels, _INT):
+            labels = [labels]
+        if single_frame:
+            region_boundingbox = True
+        bbox = bboxes = None
+        if not isinstance(region_boundingbox, bool):
+            if sum(isinstance(s, slice) for s in region_boundingbox) == 3:
+                bbox = tuple(region_boundingbox)
+            else:
+                print("TypeError: Wong type for 'region_boundingbox', should either be bool or la tuple of slices")
+                return None
+        elif region_boundingbox:
+            bbox = self.region_boundingbox(labels)
+        else:
+            bboxes = self.boundingbox(labels, real=False)
+            if not isinstance(bboxes, dict):
+                bboxes = dict(zip(labels, bboxes))
+        image, differs = np.asarray(self.image), self._layer18()
+        vox_layer = np.zeros_like(image[bbox], dtype=int) if single_frame else {}
+        clabel = None
+        for clabel in labels:
+            crop = bbox if bbox is not None else bboxes[clabel]
+            mask = image[crop] == clabel
+            edge = np.zeros(mask.shape, dtype=bool)
+            for axis in range(mask.ndim):
+                if mask.shape[axis]:
+                    first, last = [slice(None)] * mask.ndim, [slice(None)] * mask.ndim
+                    first[axis], last[axis] = 0, -1
+                    edge[tuple(first)] = True
+                    edge[tuple(last)] = True
+            layer = np.array(mask & ((differs[crop] != 0) | edge), dtype=int)
+            if single_frame:
+                vox_layer += layer
+            else:
+                vox_layer[clabel] = layer
+        if len(labels) == 1:
+            return vox_layer[clabel]
+        return vox_layer
+
     # -- wall voxels (SIA:759-880, 1049-1111): one GPU pass finds the wall voxels of EVERY pair (18-neighbourhood
     # contact, scipy's generate_binary_structure(3, 2)); the methods below are lookups in that table.
     def wall_table(self):
@@ -551,6 +654,7 @@ class AbstractSpatialImageAnalysis(object):
         self._center_of_mass = {}
         self._walls = None
         self._voxel_layer1 = None
+        self._voxel_layer18 = None
 
     def fuse_labels_in_image(self, labels, verbose=True):  # SIA:1114-1136
         """Modify the image so the given labels are fused (to the min value)."""
@@ -609,6 +713,7 @@ class SpatialImageAnalysis3D(AbstractSpatialImageAnalysis):
         AbstractSpatialImageAnalysis.__init__(self, image, ignoredlabels, return_type, background,
                                               device=device, extraction=extraction)
         self._voxel_layer1 = None
+        self._voxel_layer18 = None
 
     def is3D(self):
         return True
