@@ -10,6 +10,10 @@ reduce and the adjacency merge).  N = 1 runs BASELINE.json's metric config (C4: 
 ~50k seeds, full feature set).  N > 1 is weak scaling with the same voxel count per GPU, Z-slab
 partitioned with a one-plane halo; N = 8 is exactly config C5 (2048^3, 100k seeds).
 
+Before the W warmup steps the same step runs untimed for --settle-ms (default 200 ms; `config.settle_ms`): a chip that has
+idled -- the synthetic volume is generated and the CPU baseline computed before anything is timed -- needs tens of
+milliseconds of work to reach its sustained clock, and K steps of ~1 ms would otherwise measure the ramp.
+
 Rank 0 prints ONE JSON line (contract in the task description), with extra objects:
   roofline     -- the sweep kernel's algorithmic bytes / its mean HIP-event duration vs 8 TB/s, plus
                   `peak_measured`: what a trivial 16-B/lane read-reduce kernel reaches on the same buffer in this run
@@ -119,6 +123,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--settle-ms", type=float, default=200.0, help="untimed steps before the warmup, until the clock has settled")
     ap.add_argument("--config", default=None, help="override: C2/C3/C4/C5 on one GPU")
     ap.add_argument("--features", type=lambda v: int(v, 0), default=None,
                     help="override the feature mask (e.g. 0x0f = everything but adjacency); not the headline metric")
@@ -202,6 +207,22 @@ def main():
         for _ in range(depth):
             job.step()
         job.finish()
+    # The chip takes tens of milliseconds of work to reach its sustained clock after idling (the first 10 ms of sweeps of a
+    # process measure 3 - 4 % slower than the rest: gpurun_out/c4_tp3.txt): run the same step, untimed, for --settle-ms
+    # before the W warmup steps, so that K short steps measure the steady state and not the ramp.
+    if args.settle_ms > 0:
+        barrier()
+        t_est = time.perf_counter()
+        for _ in range(5):
+            job.step()
+        job.finish()
+        barrier()
+        est = torch.tensor([(time.perf_counter() - t_est) / 5.0], dtype=torch.float64, device="cuda:%d" % local_rank)
+        if n > 1:
+            dist.all_reduce(est, op=dist.ReduceOp.MAX)          # the same count on every rank: steps are collective
+        for _ in range(min(5000, int(args.settle_ms * 1e-3 / max(float(est.item()), 1e-6)) + 1)):
+            job.step()
+        job.finish()
     for _ in range(args.warmup):
         job.step()
     barrier()
@@ -275,6 +296,7 @@ def main():
                                    % (cfg["name"], dims[0], dims[1], dims[2], dtype.name, cfg["n_cells"],
                                       labels_present, feats, n),
                        "voxels_per_gpu": int(nvox / n), "label_dtype": dtype.name, "steps_in_flight": depth,
+                       "settle_ms": args.settle_ms,
                        "pct_hbm_roofline": round(100.0 * achieved / HBM_PEAK_GBS, 2)},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -295,9 +317,17 @@ def main():
         if n == 1 and not args.no_secondary and not args.config and args.features is None and not args.dims \
                 and not args.no_ellipsoid:
             sec = {}
+
+            def settle(step, finish):          # the headline's --settle-ms for the single-rank figures below (the host just
+                t_s = time.perf_counter()      # spent seconds on the CPU baseline: the chip is idle again)
+                while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+                    for _ in range(8):
+                        step()
+                    finish()
             # (a) two steps in flight on two streams: what N > 1 runs
             pj = tad.PipelinedSlabJob(vol, dtype.itemsize, a_origin=a_lo, has_low_halo=bool(halo), max_label=max_label,
                                       features=feats, group=None, device=local_rank, depth=2, tile_planes=args.tile_planes)
+            settle(pj.step, lambda: (pj.finish(), torch.cuda.synchronize()))
             for _ in range(args.warmup):
                 pj.step()
             pj.finish(); torch.cuda.synchronize()
@@ -316,6 +346,7 @@ def main():
             torch.cuda.synchronize()
             job2 = tad.SlabJob(ctx, vol2, dtype.itemsize, a_origin=0, has_low_halo=False, max_label=max_label,
                                features=feats, group=None, device=local_rank)
+            settle(job2.step, torch.cuda.synchronize)
             for _ in range(args.warmup):
                 job2.step()
             torch.cuda.synchronize()
@@ -353,6 +384,7 @@ def main():
                 torch.cuda.synchronize()
                 job5 = tad.SlabJob(ctx, vol5, t5.itemsize, a_origin=0, has_low_halo=False, max_label=L5, features=feats,
                                    group=None, device=local_rank)
+                settle(job5.step, torch.cuda.synchronize)
                 for _ in range(2):
                     job5.step()
                 torch.cuda.synchronize()
