@@ -7,10 +7,11 @@
 // Layout of the work.  A wave walks DOWN axis 1 over `rows_per_wave` rows of one plane, for one strip of 256 columns:
 // lane i holds the four columns c0 + 4 i .. + 3 of the 3 x 3 rows around the current one in registers -- a ring of three
 // row slots per plane, so nothing is moved; a step loads the three rows the next one will need (one 8- or 16-byte load
-// per row and lane) and leaves them as memory returned them until then -- every row is read three times in all, by the walkers of its own plane and of
-// the two planes next to it, from L2; three of the four column neighbours are the lane's own registers and the fourth
-// comes from the next lane through DPP.  Out-of-volume neighbours are handled by CLAMPING the plane / row / column
-// index: the clamped position is itself one of the 18 neighbours (or the voxel), so it adds no label.
+// per row and lane) and leaves them as memory returned them until then -- every row is read three times in all, by the
+// walkers of its own plane and of the two planes next to it, from L2; three of the four column neighbours are the lane's
+// own registers and the fourth comes from the next lane through DPP.  Out-of-volume neighbours are handled by CLAMPING
+// the plane / row / column index: the clamped position is itself one of the 18 neighbours (or the voxel), so it adds no
+// label.
 // A (row, strip) of the walk is a CELL: 256 voxels whose records are consecutive in the output.
 //
 // Distinct labels per voxel without an 18 x 18 compare: with t_q = (neighbour_q XOR l) - 1 (one v_xad_u32; a neighbour
@@ -22,8 +23,8 @@
 //
 // ONE compute pass.  COUNT finds the labels of a cell, takes room for its records in a STAGING area (a wave takes 512
 // records at a time with one returning atomic on one of 256 cursors that each own a region: no hot word, an atomic
-// every eighth cell or so) and stores them there as {label, the other label, column}
-// in memory order (lane, column, label); it leaves the cell's record count and its place in the staging area.  An
+// every eighth cell or so) and stores them there as {label, the other label, column} in memory order (lane, column,
+// label), through the wave's slice of LDS; it leaves the cell's record count and its place in the staging area.  An
 // exclusive scan ON THE DEVICE turns the counts into offsets; the host reads back ONE line (total, cells not staged,
 // wide labels seen) to size the output; COPY moves every cell's records from the staging area to its offset, adding
 // the coordinates in array-axis order -- no atomics, no second look at the volume.  A cell whose records did not fit
