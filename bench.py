@@ -25,7 +25,8 @@ Rank 0 prints ONE JSON line (contract in the task description), with extra objec
                   headline workload with two steps in flight (what N > 1 runs), so that a scaling curve compares like with
                   like; `sorted_adjacency_ms`: what a caller of ta_adjacency_get pays on top of a step (device sort by
                   (lo, hi) + fetch); `c5_single_gpu`: config C5 (2048^3, 34 GB) on this ONE GPU -- the denominator of
-                  BASELINE.json's ">= 6x at 8 GPUs", since N = 8 runs C5.
+                  BASELINE.json's ">= 6x at 8 GPUs", since N = 8 runs C5; `wall_voxels_c2`: the wall-voxel kernels (SURVEY.md
+                  §8f-3) on config C2's volume, count + scan + fetch against the volume once + 20-byte records.
                   (N > 1) `global_adjacency_gather_ms`: one SlabJob.result_arrays(), which assembles the GLOBAL pair list
                   from the ranks' private lists -- not part of a step (a step leaves private + travelling pairs per rank)
 """
@@ -404,6 +405,26 @@ def main():
                 del vol5, job5
             except Exception as e:                      # (a box with less free HBM than 34 GB + tables)
                 sec["c5_single_gpu"] = {"skipped": "%s: %s" % (type(e).__name__, str(e)[:120])}
+            # (e) the second kernel family of the build: wall voxels (18-neighbourhood, one record per voxel and neighbour label)
+            # of config C2's volume -- count + scan + fetch kernels against "the volume once + 20-byte records"
+            try:
+                c2 = synth.CONFIGS["C2"]
+                d2, t2 = c2["dims"], np.dtype(c2["dtype"])
+                vol_w, _ = dev.synth_slab(ctx, d2, t2, c2["n_cells"], c2["seed"], 0, d2[0], device=local_rank)
+                torch.cuda.synchronize()
+                ctx.set_volume_device(vol_w.data_ptr(), t2.itemsize, vol_w.shape, keep=vol_w)
+                best = None
+                for _ in range(3):
+                    lo_w, _hi_w, _co_w, ms_w = ctx.wall_voxels()
+                    best = ms_w if best is None else min(best, ms_w)
+                alg = float(d2[0]) * d2[1] * d2[2] * t2.itemsize + 20.0 * lo_w.size
+                sec["wall_voxels_c2"] = {"workload": "C2: 512^3 uint16, wall voxels of every pair (ta_wall_voxels_count + _get)",
+                                         "records": int(lo_w.size), "kernels_ms": round(best, 4),
+                                         "roofline_frac": round(alg / (best * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                         "algorithmic_bytes": int(alg)}
+                del vol_w, lo_w, _hi_w, _co_w
+            except Exception as e:
+                sec["wall_voxels_c2"] = {"skipped": "%s: %s" % (type(e).__name__, str(e)[:120])}
             out["secondary"] = sec
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_result
