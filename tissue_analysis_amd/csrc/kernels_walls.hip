@@ -28,7 +28,7 @@
 // exclusive scan ON THE DEVICE turns the counts into offsets; the host reads back ONE line (total, cells not staged,
 // wide labels seen) to size the output; COPY moves every cell's records from the staging area to its offset, adding
 // the coordinates in array-axis order -- no atomics, no second look at the volume.  A cell whose records did not fit
-// its region, or that holds a voxel with more than three neighbour labels, is NOT staged but listed: EMIT, the same
+// its region, or that holds a voxel with more than four neighbour labels, is NOT staged but listed: EMIT, the same
 // code with one listed cell per wave, recomputes exactly those cells and stores their records where they belong (a few
 // cells around points where five cells meet; noise volumes; a staging area sized for tissue, half a record per voxel).
 #include "ta_kernels.h"
@@ -120,6 +120,8 @@ __device__ __forceinline__ uint32_t wall_next_above(const uint32_t (&t)[18], uin
 // a record in the staging area, as COUNT holds it: the voxel's label, t = (the other label XOR it) - 1, its column in the
 // cell's strip; COPY, where every lane has a record, makes (lo, hi) of it
 struct WallStaged { uint32_t own, t, column; };
+// uint16 volumes: label and t fit 16 bits each (a staged t is never the wrapped one) -- 8 bytes a record instead of 12
+struct WallStagedNarrow { uint32_t own_t, column; };
 
 struct WallArgs {
     const void* vol;
@@ -129,7 +131,7 @@ struct WallArgs {
     uint32_t* cell_base;           // [cells] first staged record of the cell, WALL_NONE = not staged: written by COUNT
     uint8_t* lane_counts;          // [cells][64] records of each lane, cells that are not staged only
     const uint64_t* offsets;       // COPY / EMIT: exclusive scan of counts
-    WallStaged* stage;             // [WALL_CURSORS * region]
+    void* stage;                   // [WALL_CURSORS * region] WallStaged (uint32 volumes) / WallStagedNarrow (uint16)
     uint32_t* cursors;             // [WALL_CURSORS][32] (one 128-byte line each): records taken from each region
     uint32_t region;               // records per region
     uint32_t* status;              // [0] cells not staged  [1] a label >= 2^31 was seen by a kernel that cannot take it
@@ -142,6 +144,7 @@ struct WallArgs {
 
 constexpr int WALL_CURSORS = 256;
 constexpr uint32_t WALL_COPY_CELLS = 16;
+constexpr int WALL_KEPT = 4;           // labels of a voxel COUNT keeps in registers; a voxel with more leaves its cell to EMIT
 constexpr uint32_t WALL_PIECE = 512;   // records a wave takes from its region at a time (a cell of tissue holds ~60)
 
 // T: voxel type.  QUADS: rows start 4-element aligned and hold a multiple of 4 columns.  WIDE: labels may reach 2^31
@@ -248,9 +251,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     uint32_t cell_counts = 0, cell_firsts = WALL_NONE;
     auto flush_piece = [&]() {
         for (uint32_t r = (uint32_t)lane; r < piece_used; r += 64u) {
-            WallStaged rec;
-            rec.own = piece[r]; rec.t = piece[WALL_PIECE + r]; rec.column = piece[2u * WALL_PIECE + r];
-            A.stage[piece_at + r] = rec;
+            if (sizeof(T) == 2) {
+                WallStagedNarrow rec;
+                rec.own_t = piece[r]; rec.column = piece[WALL_PIECE + r];
+                reinterpret_cast<WallStagedNarrow*>(A.stage)[piece_at + r] = rec;
+            } else {
+                WallStaged rec;
+                rec.own = piece[r]; rec.t = piece[WALL_PIECE + r]; rec.column = piece[2u * WALL_PIECE + r];
+                reinterpret_cast<WallStaged*>(A.stage)[piece_at + r] = rec;
+            }
         }
     };
     const int32_t ma = (int32_t)a;
@@ -298,9 +307,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             out_pairs = A.out_pairs + base;
             out_coords = A.out_coords + 3 * base;
         }
-        uint32_t K[WNJ][3];                     // COUNT: the first three labels of each column, as t = (label XOR v) - 1
+        uint32_t K[WNJ][WALL_KEPT];             // COUNT: the first four labels of each column, as t = (label XOR v) - 1
         uint32_t nn = 0;                        // records of column j in byte j
-        bool many = false;                      // a voxel of this lane has more than three labels
+        bool many = false;                      // a voxel of this lane has more than four labels
         uint32_t total = 0;
 #pragma unroll
         for (int j = 0; j < WNJ; ++j) {
@@ -335,8 +344,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                 m = umax3(m, umax3(t[15] + 1u, t[16] + 1u, t[17] + 1u), 0u);
                 tmax = m - 1u;
             }
-            if (QUADS ? past : colq + (uint32_t)j > last) { tmin = WALL_NONE; tmax = WALL_NONE; }   // a column past the end of the row (clamped copies)
-            if (!EMIT) { K[j][0] = tmin; K[j][1] = 0u; K[j][2] = 0u; }
+            if (QUADS ? partial : true) {       // (a strip that ends inside the rows only: the test is per wave)
+                if (QUADS ? past : colq + (uint32_t)j > last) { tmin = WALL_NONE; tmax = WALL_NONE; }   // a column past the end of the row (clamped copies)
+            }
+            if (!EMIT) K[j][0] = tmin;          // (the others are read only where n says they were found)
             if (!__any(tmax != WALL_NONE)) continue;
             Int3 xyz;                                          // the voxel in array-axis order: one 12-byte store per record
             if (EMIT) {
@@ -372,8 +383,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
                     for (int round = 3; round < 19 && __any(d < tmax); ++round) {
                         const uint32_t nd3 = wall_next_above(t, d);
                         const bool more3 = d < tmax;
-                        if (EMIT) { if (more3) put(nd3); }
-                        d = more3 ? nd3 : d; n += more3 ? 1u : 0u; many = many || more3;
+                        if (EMIT) { if (more3) put(nd3); } else if (round == 3) K[j][3] = nd3;
+                        d = more3 ? nd3 : d; n += more3 ? 1u : 0u; many = many || (more3 && round > 3);
                     }
                 }
             }
@@ -410,7 +421,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         piece_used += cell_total;
         const bool several = __any((nn & 0xFEFEFEFEu) != 0u);          // some voxel of the cell has more than one label
         auto keep = [&](const uint32_t where, const uint32_t v, const uint32_t tk, const uint32_t column) {
-            piece[where] = v; piece[WALL_PIECE + where] = tk; piece[2u * WALL_PIECE + where] = column;    // (one address, three offsets)
+            if (sizeof(T) == 2) { piece[where] = v | (tk << 16); piece[WALL_PIECE + where] = column; }
+            else { piece[where] = v; piece[WALL_PIECE + where] = tk; piece[2u * WALL_PIECE + where] = column; }    // (one address, three offsets)
         };
 #pragma unroll
         for (int j = 0; j < WNJ; ++j) {
@@ -418,7 +430,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             if (nj > 0u) keep(at, v, K[j][0], column);
             if (several) {
 #pragma unroll
-                for (int i = 1; i < 3; ++i) {
+                for (int i = 1; i < WALL_KEPT; ++i) {
                     if (!__any(nj > (uint32_t)i)) break;
                     if (nj > (uint32_t)i) keep(at + (uint32_t)i, v, K[j][i], column);
                 }
@@ -446,6 +458,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
 }
 
 // COPY: a wave takes 16 cells -- one per lane for the bookkeeping, then four cells at a time with all lanes on their records
+template <bool NARROW>
 __global__ void __launch_bounds__(256) wall_copy_kernel(WallArgs A, uint32_t ncells) {
     const int lane = threadIdx.x & 63;
     const uint32_t first_cell = (blockIdx.x * 4u + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * WALL_COPY_CELLS;
@@ -469,6 +482,16 @@ __global__ void __launch_bounds__(256) wall_copy_kernel(WallArgs A, uint32_t nce
         c.mb = __builtin_amdgcn_readlane((int)pb, L);
         c.c0 = (uint32_t)__builtin_amdgcn_readlane((int)strip, L) * WSC;
         return c;
+    };
+    auto staged = [&](const uint32_t at) {
+        WallStaged rec;
+        if (NARROW) {
+            const WallStagedNarrow n = reinterpret_cast<const WallStagedNarrow*>(A.stage)[at];
+            rec.own = n.own_t & 0xffffu; rec.t = n.own_t >> 16; rec.column = n.column;
+        } else {
+            rec = reinterpret_cast<const WallStaged*>(A.stage)[at];
+        }
+        return rec;
     };
     auto put = [&](const Cell& c, const uint32_t r, const WallStaged& rec) {
         const int32_t mc = (int32_t)(c.c0 + rec.column);
@@ -496,13 +519,13 @@ __global__ void __launch_bounds__(256) wall_copy_kernel(WallArgs A, uint32_t nce
         }
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u)
-            if ((uint32_t)lane < c[u].n) rec[u] = A.stage[c[u].src + (uint32_t)lane];
+            if ((uint32_t)lane < c[u].n) rec[u] = staged(c[u].src + (uint32_t)lane);
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u)
             if ((uint32_t)lane < c[u].n) put(c[u], (uint32_t)lane, rec[u]);
 #pragma unroll
         for (int u = 0; u < DEPTH; ++u)
-            for (uint32_t r = (uint32_t)lane + 64u; r < c[u].n; r += 64u) put(c[u], r, A.stage[c[u].src + r]);
+            for (uint32_t r = (uint32_t)lane + 64u; r < c[u].n; r += 64u) put(c[u], r, staged(c[u].src + r));
     }
 }
 
@@ -611,7 +634,7 @@ static WallArgs wall_args(const void* vol, int64_t n0, int64_t n1, int64_t n2, c
     a.vol = vol; a.n0 = n0; a.n1 = n1; a.n2 = n2;
     a.nstrips = p.nstrips; a.rows_per_wave = p.rows_per_wave;
     a.counts = b.counts; a.cell_base = b.cell_base; a.lane_counts = b.lane_counts; a.offsets = b.offsets;
-    a.stage = (WallStaged*)b.stage; a.cursors = b.cursors; a.region = b.stage ? b.region : 0u; a.status = b.status;
+    a.stage = b.stage; a.cursors = b.cursors; a.region = b.stage ? b.region : 0u; a.status = b.status;
     a.todo = b.todo; a.ntodo = 0;
     a.out_pairs = nullptr; a.out_coords = nullptr;
     a.inv[0] = 0; a.inv[1] = 1; a.inv[2] = 2;
@@ -631,9 +654,9 @@ static void launch_wall_cells(hipStream_t s, const WallArgs& a, int itemsize, bo
 void launch_wall_count(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2, const WallBuffers& b,
                        bool wide) {
     const WallPlan p = wall_plan(n0, n1, n2);
-    (void)hipMemsetAsync(b.total, 0, 16, s);                   // total | status[2]
+    // total | status[2] | cursors: one clear (the layout of ta_api.hip's wall_bufs keeps them together)
+    (void)hipMemsetAsync(b.total, 0, (size_t)((char*)b.cursors - (char*)b.total) + (p.cells ? wall_cursor_bytes() : 0), s);
     if (p.cells == 0) return;
-    (void)hipMemsetAsync(b.cursors, 0, wall_cursor_bytes(), s);
     const WallArgs a = wall_args(vol, n0, n1, n2, p, b);
     launch_wall_cells<false>(s, a, itemsize, wide, (unsigned)((p.waves + 3) / 4));
     hipLaunchKernelGGL(wall_scan_sums_kernel, dim3((unsigned)p.scan_blocks), dim3(256), 0, s, b.counts, p.cells, b.block_sums);
@@ -648,7 +671,11 @@ void launch_wall_fetch(hipStream_t s, const void* vol, int itemsize, int64_t n0,
     WallArgs a = wall_args(vol, n0, n1, n2, p, b);
     a.out_pairs = (uint2*)out_pairs; a.out_coords = out_coords;
     for (int k = 0; k < 3; ++k) a.inv[perm[k]] = k;          // perm[k] = array axis of memory axis k
-    if (a.region) hipLaunchKernelGGL(wall_copy_kernel, dim3((unsigned)((p.cells + 4 * WALL_COPY_CELLS - 1) / (4 * WALL_COPY_CELLS))), dim3(256), 0, s, a, (uint32_t)p.cells);
+    if (a.region) {
+        const dim3 grid((unsigned)((p.cells + 4 * WALL_COPY_CELLS - 1) / (4 * WALL_COPY_CELLS)));
+        if (itemsize == 2) hipLaunchKernelGGL(wall_copy_kernel<true>, grid, dim3(256), 0, s, a, (uint32_t)p.cells);
+        else               hipLaunchKernelGGL(wall_copy_kernel<false>, grid, dim3(256), 0, s, a, (uint32_t)p.cells);
+    }
     a.ntodo = not_staged;
     if (not_staged) launch_wall_cells<true>(s, a, itemsize, wide, (not_staged + 3u) / 4u);
 }
