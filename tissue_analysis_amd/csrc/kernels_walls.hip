@@ -134,7 +134,7 @@ struct WallArgs {
     void* stage;                   // [WALL_CURSORS * region] WallStaged (uint32 volumes) / WallStagedNarrow (uint16)
     uint32_t* cursors;             // [WALL_CURSORS][32] (one 128-byte line each): records taken from each region
     uint32_t region;               // records per region
-    uint32_t* status;              // [0] cells not staged  [1] a label >= 2^31 was seen by a kernel that cannot take it
+    uint32_t* status;              // [0] cells not staged  [1] a label >= 2^31 was seen by a kernel that cannot take it  [2] OR of all labels
     uint32_t* todo;                // [cells] the cells that are not staged, in no order: written by COUNT, EMIT takes one per wave
     uint32_t ntodo;                // EMIT: how many
     uint2* out_pairs;              // [n] (lo, hi)
@@ -200,7 +200,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
     bool U3[WRING];
     WallRaw N[3];
     uint32_t HN[3];
-    uint32_t seen = 0;                 // OR of every label loaded (WIDE detection)
+    uint32_t seen = 0;                 // OR of every label of the wave's own plane (WIDE detection; how many bits a label takes)
     const uint32_t hcol = lane < 32 ? col_left : col_right;
     const bool lane_past = colq > last;
     auto load_rows = [&](const T* const (&rows)[3], WallRaw (&n)[3], uint32_t (&hn)[3]) {
@@ -222,7 +222,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         for (int p = 0; p < 3; ++p) {
             const WallQuad& q = W[p][k];
             d |= ((q.v[0] ^ ref) | (q.v[1] ^ ref)) | ((q.v[2] ^ ref) | (q.v[3] ^ ref)) | (H[p][k] ^ ref);
-            if (sizeof(T) == 4 && !WIDE && !EMIT) seen |= (q.v[0] | q.v[1]) | (q.v[2] | q.v[3]);
+            if (p == 1 && !EMIT) seen |= (q.v[0] | q.v[1]) | (q.v[2] | q.v[3]);
         }
         R3[k] = ref;
         U3[k] = !__any(d != 0u);
@@ -453,6 +453,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
         }
         if (sizeof(T) == 4 && !WIDE) {
             if (__any((int32_t)seen < 0) && lane == 0) A.status[1] = 1u;
+        }
+        {   // the bits labels occupy (the grouping sort packs its keys by it): only lanes that bring a new bit touch the word
+            const uint32_t known = *reinterpret_cast<const volatile uint32_t*>(A.status + 2);
+            if (seen & ~known) atomicOr(A.status + 2, seen);
         }
     }
 }

@@ -106,6 +106,7 @@ struct ta_ctx {
     int64_t wall_records = -1;                          // result of the last ta_wall_voxels_count, -1 = none
     uint32_t wall_region = 0, wall_not_staged = 0;      // records per staging region of that call (0 = nothing staged); cells left to the second walk
     bool wall_wide = false;                             // that call met a label >= 2^31
+    uint32_t wall_label_or = 0;                         // OR of all labels of the volume (that call): the bits a label takes
     double wall_ms = 0.0;
     int pair_log2 = 0;                                  // current table log2 capacity
     int opt_pair_log2 = 0;
@@ -638,7 +639,7 @@ TA_API int ta_volume_layer18(ta_ctx* c, uint8_t* host_dst) {
 
 namespace {
 // layout of ta_ctx::wall_counts: counts u32[cells] | cell_base u32[cells] (each padded to 8 bytes) | offsets u64[cells] |
-// block sums u64[scan_blocks] | total u64 + status u32[2] (the 16 bytes the host reads back) | cursors | todo u32[cells] |
+// block sums u64[scan_blocks] | total u64 + status u32[6] (the 32 bytes the host reads back) | cursors | todo u32[cells] |
 // lane counts u8[cells][64]
 uint64_t wall_bufs(void* base, const ta::WallPlan& p, ta::WallBuffers& b) {
     const uint64_t counts_bytes = (p.cells * 4 + 7) & ~7ull;
@@ -647,7 +648,7 @@ uint64_t wall_bufs(void* base, const ta::WallPlan& p, ta::WallBuffers& b) {
     b.cell_base = (uint32_t*)at; at += counts_bytes;
     b.offsets = (uint64_t*)at; at += p.cells * 8;
     b.block_sums = (uint64_t*)at; at += p.scan_blocks * 8;
-    b.total = (uint64_t*)at; b.status = (uint32_t*)(b.total + 1); at += 16;
+    b.total = (uint64_t*)at; b.status = (uint32_t*)(b.total + 1); at += 32;
     b.cursors = (uint32_t*)at; at += ta::wall_cursor_bytes();
     b.todo = (uint32_t*)at; at += counts_bytes;
     b.lane_counts = (uint8_t*)at; at += p.cells * 64;
@@ -693,7 +694,7 @@ TA_API int ta_wall_voxels_count(ta_ctx* c, int64_t* nrecords) {
     wall_stage(c, plan, wb);
     c->wall_region = wb.region;
     hipEvent_t e0 = nullptr, e1 = nullptr;
-    struct { uint64_t total; uint32_t not_staged, wide_seen; } line = {0, 0, 0};
+    struct { uint64_t total; uint32_t not_staged, wide_seen, label_or, unused[3]; } line = {0, 0, 0, 0, {0, 0, 0}};
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);
     float ms_all = 0.f;
@@ -706,7 +707,7 @@ TA_API int ta_wall_voxels_count(ta_ctx* c, int64_t* nrecords) {
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(&line, wb.total, 16, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&line, wb.total, 32, hipMemcpyDeviceToHost, c->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         float ms = 0.f;
         if (e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
@@ -720,6 +721,7 @@ TA_API int ta_wall_voxels_count(ta_ctx* c, int64_t* nrecords) {
     c->wall_records = (int64_t)line.total;
     c->wall_not_staged = line.not_staged;
     c->wall_wide = wide;
+    c->wall_label_or = line.label_or;
     c->wall_ms = ms_all;
     if (getenv("TA_WALL_VERBOSE"))
         fprintf(stderr, "[tissue_scan] wall voxels: %llu records in %llu cells of 256 voxels, %u cells not staged (regions of %u records), wide=%d, %.3f ms\n",
@@ -770,7 +772,8 @@ int wall_voxels_fetch(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_ou
         uint64_t* k1 = (uint64_t*)p; p += rec;
         uint32_t* i0 = (uint32_t*)p; p += ix;
         uint32_t* i1 = (uint32_t*)p; p += ix;
-        const int label_bits = c->itemsize == 2 ? 16 : 32;          // bits a label of this volume can occupy
+        int label_bits = 1;                                         // bits a label of this volume takes
+        while (label_bits < 32 && (c->wall_label_or >> label_bits) != 0u) ++label_bits;
         e = ta::launch_wall_group_by_pair(c->stream, dpa, dco, n, k0, k1, i0, i1, p, temp_bytes, label_bits, gpa, gco);
     }
     if (e == hipSuccess) e = hipEventRecord(e1, c->stream);

@@ -46,7 +46,7 @@ struct WallBuffers {
     uint8_t* lane_counts;    // [cells][64]
     uint64_t* offsets;       // [cells]
     uint64_t* block_sums;    // [scan_blocks]
-    uint64_t* total;         // total u64 | status u32[2] (cells not staged, wide label seen): the line the host reads back
+    uint64_t* total;         // total u64 | status u32[6] (cells not staged, wide label seen, OR of all labels, -): the 32-byte line the host reads back
     uint32_t* status;        // = (uint32_t*)(total + 1)
     void* stage;             // wall_stage_bytes(region) or NULL: nothing is staged, every cell takes the second walk
     uint32_t* cursors;       // wall_cursor_bytes()
@@ -65,7 +65,7 @@ void launch_wall_fetch(hipStream_t s, const void* vol, int itemsize, int64_t n0,
 uint64_t wall_sort_temp_bytes(uint64_t n);
 hipError_t launch_wall_group_by_pair(hipStream_t s, const uint32_t* pairs, const int32_t* coords, uint64_t n, uint64_t* keys0,
                                      uint64_t* keys1, uint32_t* index0, uint32_t* index1, void* temp, uint64_t temp_bytes,
-                                     int key_bits_lo, uint32_t* pairs_out, int32_t* coords_out);
+                                     int label_bits, uint32_t* pairs_out, int32_t* coords_out);
 
 // kernels_walls.hip (continued): exclusive scan of uint32 counts into uint64 offsets (three small kernels)
 uint64_t scan_u32_scratch_bytes(uint64_t n);
