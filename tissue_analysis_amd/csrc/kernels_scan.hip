@@ -59,14 +59,20 @@ struct __attribute__((aligned(16))) ScanWaveLds {
     uint32_t cql[RCAP + 2], cqc[RCAP + 2];              // runs; record i lives in slot i + 1, slot 0 = sentinel / carry, slot RCAP + 1 = trash
 };
 
-template <int NW, bool ADJ>
+// NBUF record buffers per producer wave.  NBUF = 1: the wave that fills its buffers also drains them.  NBUF > 1: the workgroup
+// has one more wave, the CONSUMER, which drains the buffers the WAVES producers hand over (see consumer_loop): `ctl` holds
+// one word per buffer (0 = free for the producer, else FULL | counts) and one per producer ("no more buffers will come").
+constexpr uint32_t CTL_FULL = 0x80000000u, CTL_KEEP = 0x40000000u;       // | faces | runs to consume << 12
+template <int NW, bool ADJ, int NBUF = 1>
 struct __attribute__((aligned(16))) ScanLds {
-    ScanWaveLds<ADJ> wave[WAVES];
+    ScanWaveLds<ADJ> wave[WAVES * NBUF];
     uint64_t lsum[LSLOTS * NW];
     uint64_t pkeys[ADJ ? PSLOTS : 2];
+    uint64_t pcnt[ADJ ? PSLOTS : 1];  // three 21-bit face counts per pair (PCNT_BITS)
     uint32_t lbox[LSLOTS * 8];
     uint32_t lkeys[LSLOTS];
-    uint32_t pcnt[ADJ ? PSLOTS * 3 : 1];
+    uint32_t ctl[NBUF > 1 ? WAVES * NBUF + WAVES : 1];
+    uint32_t lead[NBUF > 1 ? WAVES : 1];      // the leading label of each producer's tile (its first voxel)
     uint32_t frame[4];                // origin (axes 0, 1, 2) of the tile-local coordinates: only the spill paths need it
 #ifdef TA_LDS_PAD
     uint32_t pad_[TA_LDS_PAD];        // experiments only: fewer workgroups per CU
@@ -189,7 +195,7 @@ __device__ __forceinline__ void scan_pair_add(const SweepArgs* kp, LDS& S, uint3
         h = (h + 1) & (PSLOTS - 1);
         k = S.pkeys[h];
     }
-    if (slot >= 0) atomicAdd(&S.pcnt[slot * 3 + axis], 1u);
+    if (slot >= 0) atomicAdd((unsigned long long*)&S.pcnt[slot], 1ull << (PCNT_BITS * axis));
     else {
         const SweepArgs* A = cold_args(kp);
         pair_spill_global(A->pairs, A->flags, lo, hi, axis, 1u);
@@ -226,11 +232,12 @@ __device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S,
 }
 
 // Drain both buffers of a wave completely, 64 records per pass, every lane busy but in the last pass.
-template <bool ADJ, bool MOM2, typename LDS>
-__device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
-                                              const bool EDGE, int w, int lane, uint32_t& fcount, uint32_t& rcount,
-                                              const uint32_t lead_label, const bool may_keep) {
-    auto& W = S.wave[w];
+// CONS (the consumer wave's instance): `keep_in` says whether the last record stays behind (the producer has moved it to its
+// next buffer and seeded that buffer's carry slot already): nothing is written back into the buffer.
+template <bool ADJ, bool MOM2, bool CONS, typename LDS, typename WLDS>
+__device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S, WLDS& W,
+                                              const bool EDGE, int lane, uint32_t& fcount, uint32_t& rcount,
+                                              const uint32_t lead_label, const bool may_keep, const uint32_t keep_in = 0u) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (TA_ABLATE >= 1) { fcount = 0u; rcount = 0u; return; }
     if (ADJ) {
@@ -256,8 +263,8 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
     // except when a row too big for the buffers is placed a lane range at a time (place_in_pieces).
     // (`may_keep`: only there.  Everywhere else a last record without a follower is complete as it is: the boundary with the
     //  tile on the left in a row that has no closing record.)
-    uint32_t keep = 0u;
-    if (ADJ && may_keep && rcount) keep = (__builtin_amdgcn_readfirstlane((int)W.cqc[rcount]) & ROW_END) ? 0u : 1u;
+    uint32_t keep = CONS ? keep_in : 0u;
+    if (!CONS && ADJ && may_keep && rcount) keep = (__builtin_amdgcn_readfirstlane((int)W.cqc[rcount]) & ROW_END) ? 0u : 1u;
     const uint32_t nrun = rcount - keep;
     for (uint32_t i = 0; i < nrun; i += 64u) {
         const uint32_t idx = i + (uint32_t)lane;
@@ -280,7 +287,7 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S,
             consume_scan_run<MOM2, LDS>(kp, S, EDGE, label, s, code, lh, lk);
         }
     }
-    if (rcount) {
+    if (!CONS && rcount) {
         // carry: the record that follows (if it belongs to the same row) starts where the last consumed one ended; a record
         // that stays behind moves to the front
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -371,14 +378,19 @@ __device__ __forceinline__ void unpack_strip(const u32x4& x, uint32_t (&dst)[VPL
 // column to the left.  PINB: 0 = plain guarded loads (volumes whose rows are not 16-byte aligned), else the first of the
 // hand-pinned registers the plane in flight lands in.  EDGE with PINB != 0 is the PADDED variant: interior-style loads from
 // clamped addresses, the positions outside the volume overwritten with the filler when the plane lands.
-template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, typename LDS>
+// NBUF > 1: the wave only PRODUCES records; a buffer that cannot take the next row's records is handed over to the
+// workgroup's consumer wave and the wave goes on in its next buffer (it waits only when that one has not been drained yet).
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, int NBUF, typename LDS>
 __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* kp, LDS& S, const int lane, const int w,
                                           const uint32_t c_tile0, const uint32_t b_tile0,
                                           const int32_t p_lo, const int32_t p_hi) {
     constexpr int TC = 64 * VPL;
+    constexpr bool HANDOVER = NBUF > 1;
     static_assert(TC <= 512, "the run code holds the end column in 10 bits");
     static_assert(FCAP >= RB * VPL && RCAP >= VPL + 1, "the records of one lane must fit a buffer");
-    auto& W = S.wave[w];
+    static_assert(!HANDOVER || (ADJ && FCAP < 4096 && RCAP < 4096), "the hand-over word holds two 12-bit counts");
+    uint32_t bufsel = 0u;                                  // HANDOVER: which of the wave's NBUF buffers is being filled
+    auto* Wp = &S.wave[w * NBUF];
 
     const T* vol = reinterpret_cast<const T*>(A.vol);
     const int64_t n1 = A.n1, n2 = A.n2, plane = n1 * n2;
@@ -486,13 +498,13 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #ifdef TA_STAMPS
     uint64_t tk_cmp = 0, tk_emit = 0, tk_drain = 0, tk_adv = 0, tk_land = 0, tk_evrows = 0, tk_drains = 0;
 #endif
-    if (lane == 0) W.cqc[0] = NO_ROW;
+    if (lane == 0) Wp->cqc[0] = NO_ROW;
     // LDS byte offsets of the wave's buffers (the low half of a flat LDS address is the LDS offset)
-    const uint32_t fbase = (uint32_t)(uintptr_t)&W.frec[0];
-    const uint32_t rbase = (uint32_t)(uintptr_t)&W.cql[1];
+    uint32_t fbase = (uint32_t)(uintptr_t)&Wp->frec[0];
+    uint32_t rbase = (uint32_t)(uintptr_t)&Wp->cql[1];
     constexpr uint32_t RSTRIDE = (RCAP + 2) * 4u;         // bytes between the two run arrays
-    const uint32_t ftrash = (uint32_t)(uintptr_t)&W.frec[FTRASH];   // where the stores of compares that did not fire go
-    const uint32_t rtrash = (uint32_t)(uintptr_t)&W.cql[RTRASH];
+    uint32_t ftrash = (uint32_t)(uintptr_t)&Wp->frec[FTRASH];   // where the stores of compares that did not fire go
+    uint32_t rtrash = (uint32_t)(uintptr_t)&Wp->cql[RTRASH];
 
     // Leading rows of the tile that are one label (the label of its first voxel) from end to end are not records:
     // they are counted and added in closed form at the end -- that is the whole cost of background.
@@ -506,7 +518,36 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #ifdef TA_RECCOUNT
         if (lane == 0) { atomicAdd(&cold_args(kp)->flags[8], fcount); atomicAdd(&cold_args(kp)->flags[9], rcount); atomicAdd(&cold_args(kp)->flags[10], 1u); }
 #endif
-        drain_buffers<ADJ, MOM2, LDS>(kp, S, EDGE, w, lane, fcount, rcount, first_label, may_keep);
+        if constexpr (!HANDOVER) {
+            drain_buffers<ADJ, MOM2, false, LDS>(kp, S, *Wp, EDGE, lane, fcount, rcount, first_label, may_keep);
+        } else {
+            // Hand the buffer over to the consumer wave and go on in the next one.  A boundary record whose follower has not
+            // been placed yet (may_keep) moves to the front of the next buffer; the consumer is told to leave it alone.
+            if (fcount == 0u && rcount == 0u) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            uint32_t keep = 0u;
+            if (may_keep && rcount) keep = (__builtin_amdgcn_readfirstlane((int)Wp->cqc[rcount]) & ROW_END) ? 0u : 1u;
+            const uint32_t nrun = rcount - keep;
+            const uint32_t nsel = bufsel + 1u == (uint32_t)NBUF ? 0u : bufsel + 1u;
+            auto* Wn = &S.wave[w * NBUF + (int)nsel];
+            uint32_t* const ctl_next = &S.ctl[w * NBUF + (int)nsel];
+            // (the next buffer is free once the consumer has written 0 over its word; the load is wave-uniform)
+            while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctl_next, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0)
+                __builtin_amdgcn_s_sleep(2);
+            if (lane == 0) {
+                // carry: the record that follows (if it belongs to the same row) starts where the last consumed one ended
+                const uint32_t carry = Wp->cqc[nrun];
+                if (keep) { const uint32_t kl = Wp->cql[rcount], kc = Wp->cqc[rcount]; Wn->cql[1] = kl; Wn->cqc[1] = kc; }
+                Wn->cqc[0] = carry;
+                __hip_atomic_store(&S.ctl[w * NBUF + (int)bufsel], CTL_FULL | (keep ? CTL_KEEP : 0u) | fcount | (nrun << 12),
+                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            bufsel = nsel; Wp = Wn;
+            fbase = (uint32_t)(uintptr_t)&Wp->frec[0]; rbase = (uint32_t)(uintptr_t)&Wp->cql[1];
+            ftrash = (uint32_t)(uintptr_t)&Wp->frec[FTRASH]; rtrash = (uint32_t)(uintptr_t)&Wp->cql[RTRASH];
+            fcount = 0u; rcount = keep;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        }
 #ifdef TA_STAMPS
         tk_drain += __builtin_amdgcn_s_memtime() - td0; tk_drains += 1;
 #endif
@@ -645,7 +686,10 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             }
             leftv = nxt_leftv;
         }
-        if (p == p_lo) first_label = __builtin_amdgcn_readfirstlane(cur[0][0]);
+        if (p == p_lo) {
+            first_label = __builtin_amdgcn_readfirstlane(cur[0][0]);
+            if (HANDOVER && lane == 0) S.lead[w] = first_label;          // (published with the first buffer handed over)
+        }
         const bool with_plane_faces = ADJ && (p > p_lo || has_prev);
         const uint32_t cf_plane = with_plane_faces ? count_plane_faces() : 0u;
 #ifdef TA_STAMPS
@@ -768,6 +812,8 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 
     // ---- end of tile: drain the buffers, then the leading one-label rows in one closed form
     drain(false);
+    if (HANDOVER && lane == 0)         // no more buffers will come from this wave
+        __hip_atomic_store(&S.ctl[WAVES * NBUF + w], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (__builtin_amdgcn_ballot_w64(bad)) { if (lane == 0) atomicOr(&cold_args(kp)->flags[FLAG_RANGE], 1u); }
     if (lane == 0 && nlead != 0u && first_label != INVALID_LABEL) {
         // rows in (plane, row) order: P full planes of RB rows, then R rows of plane P
@@ -795,6 +841,42 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     }
 }
 
+// The consumer wave of a workgroup whose producers hand their buffers over (NBUF > 1): it polls the control words -- lane i
+// reads word i: one LDS read per poll -- drains the full buffers round-robin and leaves once every producer has said that no
+// more will come and a later poll has found no full buffer (a producer publishes its last buffer BEFORE that word).
+template <bool MOM2, int NBUF, typename LDS>
+__device__ __forceinline__ void consumer_loop(const SweepArgs* kp, LDS& S, const int lane) {
+    constexpr uint32_t NB = WAVES * NBUF;
+    uint32_t rot = 0u;
+    bool confirmed = false;
+    for (;;) {
+        uint32_t word = 0u;
+        if (lane < (int)(NB + WAVES)) word = __hip_atomic_load(&S.ctl[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const uint64_t nz = __builtin_amdgcn_ballot_w64(word != 0u);
+        const uint32_t full = (uint32_t)nz & ((1u << NB) - 1u);
+        if (full) {
+            const uint32_t later = full >> rot << rot;                      // the full buffers at or after `rot`
+            const uint32_t b = (uint32_t)__builtin_ctz(later ? later : full);
+            const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)b);
+            const uint32_t keep = (cw & CTL_KEEP) ? 1u : 0u;
+            uint32_t fcount = cw & 0xfffu, rcount = ((cw >> 12) & 0xfffu) + keep;
+            const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.lead[b / (uint32_t)NBUF]);
+            drain_buffers<true, MOM2, true, LDS>(kp, S, S.wave[b], false, lane, fcount, rcount, lead, false, keep);
+            if (lane == 0) __hip_atomic_store(&S.ctl[b], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            rot = b + 1u == NB ? 0u : b + 1u;
+            confirmed = false;
+            continue;
+        }
+        if ((uint32_t)(nz >> NB) == (1u << WAVES) - 1u) {
+            if (confirmed) break;
+            confirmed = true;
+            continue;
+        }
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+
 // Tiles of a volume: `fc` x `fb` full tiles per plane band go to the interior kernel (hand-issued 16-byte loads, no
 // bounds); the partial tiles of the last tile column / tile row go to the PADDED kernel (the same loads from clamped
 // addresses, filler written over what lies outside) when 16-byte loads are allowed (SweepArgs::vec_ok), else everything
@@ -816,19 +898,21 @@ static ScanSplit scan_split(const SweepArgs& a, int itemsize) {
     return s;
 }
 
-template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB>
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, int NBUF = 1>
 __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanSplit& sp, const uint32_t wg0) {
     constexpr int NW = MOM2 ? 6 : 2;
     constexpr int TC = 64 * VPL, TB = WAVES * RB;
+    constexpr int NT = (WAVES + (NBUF > 1 ? 1 : 0)) * 64;          // threads: the producers (+ the consumer wave)
     static_assert(TB <= 16 && TC <= 512, "packed LDS moment words assume <= 16 rows x 512 columns per tile");
-    using LDS = ScanLds<NW, ADJ>;
+    using LDS = ScanLds<NW, ADJ, NBUF>;
+    static_assert(NBUF == 1 || sizeof(LDS) <= 40960, "four workgroups with a consumer wave must fit the 160 KB of a CU");
     __shared__ LDS S;
     // the arguments only the cold paths need are re-read from the kernarg segment there (see cold_args)
     const SweepArgs* kp = kernarg_args(A);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < LSLOTS; i += WAVES * 64) {
+    for (int i = tid; i < LSLOTS; i += NT) {
         S.lkeys[i] = INVALID_LABEL;
 #pragma unroll
         for (int k = 0; k < NW; ++k) S.lsum[i * NW + k] = 0ull;
@@ -836,10 +920,13 @@ __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanS
         S.lbox[i * 8 + 3] = 0u; S.lbox[i * 8 + 4] = 0u; S.lbox[i * 8 + 5] = 0u;
     }
     if (ADJ) {
-        for (int i = tid; i < PSLOTS; i += WAVES * 64) {
+        for (int i = tid; i < PSLOTS; i += NT) {
             S.pkeys[i] = EMPTY_KEY;
-            S.pcnt[i * 3 + 0] = 0u; S.pcnt[i * 3 + 1] = 0u; S.pcnt[i * 3 + 2] = 0u;
+            S.pcnt[i] = 0ull;
         }
+    }
+    if (NBUF > 1) {
+        if (tid < WAVES * NBUF + WAVES) S.ctl[tid] = 0u;
     }
     const uint32_t wg = wg0 + blockIdx.x;
     if (TA_HOT_ADJ || !ADJ) hot_row_init(A, tid, wg);
@@ -875,14 +962,16 @@ __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanS
     if (tid == 0) { S.frame[0] = (uint32_t)A0; S.frame[1] = b_tile0; S.frame[2] = c_tile0; }
     __syncthreads();
 
-    if (p_lo < p_hi)
-        wave_scan<T, VPL, RB, ADJ, MOM2, EDGE, PINB>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
+    if (p_lo < p_hi) {
+        if (NBUF > 1 && w == WAVES) consumer_loop<MOM2, NBUF>(kp, S, lane);
+        else wave_scan<T, VPL, RB, ADJ, MOM2, EDGE, PINB, NBUF>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
+    }
     __syncthreads();
     // (everything the flush needs is re-read -- arguments from the kernarg segment, the tile origin from LDS --
     //  rather than kept in scarce SGPRs across the sweep)
     const SweepArgs& Ac = *cold_args(kp);
     const uint32_t wg_ = reinterpret_cast<const uint32_t*>(&Ac + 1)[sizeof(ScanSplit) / 4] + blockIdx.x;     // wg0 + block
-    flush_tables<NW, ADJ, MOM2, (TA_HOT_ADJ || !ADJ)>(Ac, S, threadIdx.x, (uint64_t)S.frame[0], (uint64_t)S.frame[1], (uint64_t)S.frame[2],
+    flush_tables<NW, ADJ, MOM2, (TA_HOT_ADJ || !ADJ), LDS, NT>(Ac, S, threadIdx.x, (uint64_t)S.frame[0], (uint64_t)S.frame[1], (uint64_t)S.frame[2],
                                       (TA_HOT_ADJ || !ADJ) ? hot_label_of<T>(Ac) : 0u, wg_);
 }
 
@@ -892,10 +981,14 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_
     scan_kernel_body<T, VPL, RB, true, MOM2, EDGE, EDGE ? 0 : TA_PIN_ADJ>(A, sp, wg0);
 }
 // the full tiles of a uint32 volume with adjacency: two rows per wave, five waves per SIMD
+#ifndef TA_NBUF
+#define TA_NBUF 2         // record buffers per producer wave of the kernel with a consumer wave (1 = no consumer wave)
+#endif
+constexpr int TWO_ROWS_THREADS = (WAVES + (TA_NBUF > 1 ? 1 : 0)) * 64;
 template <typename T, int VPL, int RB, bool MOM2>
-__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ2))) scan_two_rows_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+__global__ void __launch_bounds__(TWO_ROWS_THREADS) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ2))) scan_two_rows_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
     static_assert(RB == 2 && sizeof(T) == 4, "the 13-register landing zone holds two rows of a uint32 volume");
-    scan_kernel_body<T, VPL, RB, true, MOM2, false, TA_PIN_ADJ2>(A, sp, wg0);
+    scan_kernel_body<T, VPL, RB, true, MOM2, false, TA_PIN_ADJ2, TA_NBUF>(A, sp, wg0);
 }
 template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_MOM))) scan_noadj_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
@@ -924,7 +1017,7 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_star
     hipEvent_t ed0 = n_in ? nullptr : ev_start, ed1 = ev_stop;              // edge launch
     if constexpr (ADJ) {
         if constexpr (sizeof(T) == 4 && RB == 2) {
-            if (n_in) hipExtLaunchKernelGGL((scan_two_rows_kernel<T, VPL, RB, MOM2>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
+            if (n_in) hipExtLaunchKernelGGL((scan_two_rows_kernel<T, VPL, RB, MOM2>), dim3(n_in), dim3(TWO_ROWS_THREADS), 0, s, in0, in1, 0, a, sp, 0u);
         } else {
             if (n_in) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
         }

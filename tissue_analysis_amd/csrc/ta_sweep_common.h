@@ -19,7 +19,7 @@ namespace ta {
 #ifndef TA_LSLOTS
 #define TA_LSLOTS 128
 #endif
-constexpr int WAVES = TA_WAVES;   // waves per workgroup, stacked along axis 1
+constexpr int WAVES = TA_WAVES;   // PRODUCER waves per workgroup, stacked along axis 1 (a kernel with a consumer wave has one more)
 constexpr int LSLOTS = TA_LSLOTS; // label table slots per workgroup
 constexpr int PSLOTS = TA_PSLOTS; // pair table slots per workgroup
 constexpr int ilog2_c(int v) { return v <= 1 ? 0 : 1 + ilog2_c(v >> 1); }
@@ -29,6 +29,10 @@ constexpr int LPROBE = 16;        // max probes before spilling to global atomic
 constexpr int PPROBE = 32;
 constexpr int MAX_TILE_PLANES = 64;
 constexpr uint32_t LABEL_LIMIT = 1u << 28;    // max_label < 2^28: the two top bits of a record word are free
+// a pair's three per-axis face counts of ONE tile share a u64 LDS word, 21 bits each (a tile holds at most
+// 16 rows x 512 columns x 64 planes = 2^19 voxels, so a field cannot carry into the next): one table of 8 bytes per slot
+constexpr int PCNT_BITS = 21;
+constexpr uint64_t PCNT_MASK = (1ull << PCNT_BITS) - 1ull;
 
 __device__ __forceinline__ uint32_t lane_shr1(uint32_t src, uint32_t lane0_value) {
     // lane i <- src of lane i-1 ; lane 0 keeps lane0_value   (DPP wave_shr:1)
@@ -116,12 +120,12 @@ __device__ __forceinline__ void hot_row_init(const SweepArgs& A, const int tid, 
 __device__ __forceinline__ void hot_row_init(const SweepArgs& A, const int tid) { hot_row_init(A, tid, blockIdx.x); }
 
 // HOT = false compiles the hot-row path out (the naive cross-check kernel's rows; the sweep uses it for every mask).
-template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS>
+template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS, int NT = WAVES * 64>
 __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const int tid, const uint64_t A0,
                                              const uint64_t B0, const uint64_t C0, const uint32_t hot,
                                              const uint32_t wg) {
     uint64_t* const hot_rows = HOT ? hot_rows_of(A) : nullptr;
-    for (int i = tid; i < LSLOTS; i += WAVES * 64) {
+    for (int i = tid; i < LSLOTS; i += NT) {
         const uint32_t label = S.lkeys[i];
         if (label == INVALID_LABEL) continue;
         if (label > A.max_label) { atomicOr(&A.flags[FLAG_RANGE], 1u); continue; }
@@ -150,11 +154,12 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
         atomicMin(box + 2, (int32_t)(C0 + S.lbox[i * 8 + 2])); atomicMin(box + 5, -(int32_t)(C0 + S.lbox[i * 8 + 5]));
     }
     if (ADJ) {
-        for (int i = tid; i < PSLOTS; i += WAVES * 64) {
+        for (int i = tid; i < PSLOTS; i += NT) {
             const uint64_t key = S.pkeys[i];
             if (key == EMPTY_KEY) continue;
-            pair_add_global(A.pairs, (uint32_t)(key >> 32), (uint32_t)key, S.pcnt[i * 3 + 0],
-                            S.pcnt[i * 3 + 1], S.pcnt[i * 3 + 2], A.flags);
+            const uint64_t c = S.pcnt[i];
+            pair_add_global(A.pairs, (uint32_t)(key >> 32), (uint32_t)key, c & PCNT_MASK,
+                            (c >> PCNT_BITS) & PCNT_MASK, c >> (2 * PCNT_BITS), A.flags);
         }
     }
 }
