@@ -22,7 +22,7 @@ procs, objs = [], []
 for src in B.SOURCES:
     o = os.path.join(out_dir, src.replace(".hip", ".o"))
     objs.append(o)
-    cmd = [hipcc] + B.FLAGS + defs + ["-c", os.path.join(B.CSRC, src), "-o", o]
+    cmd = [hipcc] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + defs + ["-c", os.path.join(B.CSRC, src), "-o", o]
     if src == "kernels_scan.hip":
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=out_dir)))

@@ -18,6 +18,10 @@ SOURCES = ["ta_api.hip", "kernels_basic.hip", "kernels_scan.hip", "kernels_walls
 HEADERS = ["ta_device.h", "ta_kernels.h", "ta_sweep_common.h", "ta_pin_tables.inc", os.path.join("..", "..", "include", "tissue_scan.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-DTA_BUILD"]
+# The sweep kernels live on a hand-set VGPR budget (the plane in flight is pinned above it): machine LICM would hoist a dozen
+# constant materialisations (v_mov of 0 / 1 / -1 / masks for the LDS atomics of the drains) out of the plane loop and keep
+# them in registers for the whole kernel -- it cannot see that the budget is tight.
+EXTRA_FLAGS = {"kernels_scan.hip": ["-mllvm", "-disable-machine-licm"]}
 
 
 def _hipcc():
@@ -40,7 +44,7 @@ def _check_pinned(hipcc, verbose=False):
     interior kernel (or of a device function they call) reaches them."""
     import re
     asm = os.path.join(OBJDIR, "kernels_scan.check.s")
-    cmd = [hipcc] + FLAGS + ["--cuda-device-only", "-S", os.path.join(CSRC, "kernels_scan.hip"), "-o", asm]
+    cmd = [hipcc] + FLAGS + EXTRA_FLAGS["kernels_scan.hip"] + ["--cuda-device-only", "-S", os.path.join(CSRC, "kernels_scan.hip"), "-o", asm]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd, cwd=OBJDIR)
@@ -99,7 +103,7 @@ def build(force=False, save_temps=False, verbose=False):
         o = os.path.join(OBJDIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if save_temps:
                 cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
             if verbose:
@@ -155,7 +159,7 @@ def build_sanitized(force=False, verbose=False):
         o = os.path.join(ASAN_DIR, src.replace(".hip", ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            cmd = [hipcc] + flags + ["-c", s, "-o", o]
+            cmd = [hipcc] + flags + EXTRA_FLAGS.get(src, []) + ["-c", s, "-o", o]
             if verbose:
                 print(" ".join(cmd))
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=ASAN_DIR)))

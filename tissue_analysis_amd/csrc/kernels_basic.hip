@@ -18,6 +18,7 @@ __global__ void __launch_bounds__(256) init_kernel(uint64_t* sums, int32_t* boxe
     int2* b2 = reinterpret_cast<int2*>(boxes);
     for (uint64_t i = tid; i < nbox2; i += nthreads) b2[i] = make_int2(INT32_MAX, INT32_MAX);
     if (tid < NFLAGS) flags[tid] = 0u;
+    if (tid < NQUEUES) flags[QUEUE_WORD + tid] = 0u;        // the tile queues of the persistent sweep kernel
     if (tid == 0) {
         *cursor = 0u;
         *reinterpret_cast<uint64_t**>(flags + HOT_PTR_WORD) = hot_rows;      // parked for the sweep kernels

@@ -59,25 +59,34 @@ struct __attribute__((aligned(16))) ScanWaveLds {
     uint32_t cql[RCAP + 2], cqc[RCAP + 2];              // runs; record i lives in slot i + 1, slot 0 = sentinel / carry, slot RCAP + 1 = trash
 };
 
-// NBUF record buffers per producer wave.  NBUF = 1: the wave that fills its buffers also drains them.  NBUF > 1: the workgroup
-// has one more wave, the CONSUMER, which drains the buffers the WAVES producers hand over (see consumer_loop): `ctl` holds
-// one word per buffer (0 = free for the producer, else FULL | counts) and one per producer ("no more buffers will come").
-constexpr uint32_t CTL_FULL = 0x80000000u, CTL_KEEP = 0x40000000u;       // | faces | runs to consume << 12
-template <int NW, bool ADJ, int NBUF = 1>
+template <int NW, bool ADJ>
 struct __attribute__((aligned(16))) ScanLds {
-    ScanWaveLds<ADJ> wave[WAVES * NBUF];
+    ScanWaveLds<ADJ> wave[WAVES];
     uint64_t lsum[LSLOTS * NW];
     uint64_t pkeys[ADJ ? PSLOTS : 2];
+#if TA_PCNT64
     uint64_t pcnt[ADJ ? PSLOTS : 1];  // three 21-bit face counts per pair (PCNT_BITS)
+#else
+    uint32_t pcnt[ADJ ? PSLOTS * 3 : 1];
+#endif
     uint32_t lbox[LSLOTS * 8];
     uint32_t lkeys[LSLOTS];
-    uint32_t ctl[NBUF > 1 ? WAVES * NBUF + WAVES : 1];
-    uint32_t lead[NBUF > 1 ? WAVES : 1];      // the leading label of each producer's tile (its first voxel)
     uint32_t frame[4];                // origin (axes 0, 1, 2) of the tile-local coordinates: only the spill paths need it
 #ifdef TA_LDS_PAD
     uint32_t pad_[TA_LDS_PAD];        // experiments only: fewer workgroups per CU
 #endif
 };
+
+// one face of `axis` for the pair in `slot`.  (Three u32 counters: an LDS atomic on 64 bits costs the CU's LDS twice the
+// cycles per lane that shares its address -- profiles/r04_lds_atomics_microbench.txt -- and a pass of 64 faces holds few pairs.)
+template <typename LDS>
+__device__ __forceinline__ void pcnt_add(LDS& S, const uint32_t slot, const uint32_t axis) {
+#if TA_PCNT64
+    atomicAdd((unsigned long long*)&S.pcnt[slot], 1ull << (PCNT_BITS * axis));
+#else
+    atomicAdd(&S.pcnt[slot * 3u + axis], 1u);
+#endif
+}
 
 // inclusive add-scan over the 64 lanes: row_shr 1,2,4,8 then the two row broadcasts
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
@@ -144,9 +153,15 @@ __device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S,
     }
     if (slot >= 0) {
         unsigned long long* row = (unsigned long long*)&S.lsum[slot * NW];
+#ifndef TA_ABL_NOSUMS          // (ablations: results wrong by construction, only the time matters)
         atomicAdd(row + 0, (unsigned long long)((uint64_t)L.n | ((uint64_t)L.sb << 32)));
         atomicAdd(row + 1, (unsigned long long)((uint64_t)L.sa | ((uint64_t)L.sc << 32)));
+#endif
+#ifdef TA_ABL_NOSUMS
+        if (false) {
+#else
         if (MOM2) {
+#endif
             atomicAdd(row + 2, (unsigned long long)((uint64_t)L.saa | ((uint64_t)L.sab << 32)));
             atomicAdd(row + 3, (unsigned long long)((uint64_t)L.sbb | ((uint64_t)L.sbc << 32)));
             atomicAdd(row + (MOM2 ? 4 : 0), (unsigned long long)L.sac);
@@ -158,7 +173,11 @@ __device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S,
         const uint2 cur2 = *reinterpret_cast<const uint2*>(box + 4);     // max b,c
         // (one test for "this contribution extends the box somewhere": six separately guarded atomics are six exec-mask
         //  round trips per pass, and almost every run lies inside the box its label already has)
+#ifdef TA_ABL_NOBOX
+        const bool grows = (mna + cur.x + cur2.x == 0x12345u);
+#else
         const bool grows = (mna < cur.x) | (mnb < cur.y) | (mnc < cur.z) | (mxa > cur.w) | (mxb > cur2.x) | (mxc > cur2.y);
+#endif
         if (grows) {
             atomicMin(box + 0, mna); atomicMin(box + 1, mnb); atomicMin(box + 2, mnc);
             atomicMax(box + 3, mxa); atomicMax(box + 4, mxb); atomicMax(box + 5, mxc);
@@ -195,26 +214,20 @@ __device__ __forceinline__ void scan_pair_add(const SweepArgs* kp, LDS& S, uint3
         h = (h + 1) & (PSLOTS - 1);
         k = S.pkeys[h];
     }
-    if (slot >= 0) atomicAdd((unsigned long long*)&S.pcnt[slot], 1ull << (PCNT_BITS * axis));
+#ifdef TA_ABL_NOPCNT
+    if (slot >= 0) { if (axis == 77u) S.pcnt[slot] = 0; }
+#else
+    if (slot >= 0) pcnt_add(S, (uint32_t)slot, axis);
+#endif
     else {
         const SweepArgs* A = cold_args(kp);
         pair_spill_global(A->pairs, A->flags, lo, hi, axis, 1u);
     }
 }
 
-// one run [s, k) of a row (tile-local a, b): ten sums, every term < 2^32, every factor < 2^24
-template <bool MOM2, typename LDS>
-__device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S,
-                                                 const bool EDGE, uint32_t label, uint32_t s, uint32_t code, uint32_t lh,
-                                                 uint32_t lk) {
-    const uint32_t c0 = s, k = code & 1023u, bl = (code >> 10) & 15u, al = (code >> 14) & 63u;
-    const uint32_t n = k - c0;
-    if (label >= LABEL_LIMIT) {
-        // a real voxel the records cannot carry; INVALID_LABEL is the outside-the-volume filler of edge tiles only
-        if (label != INVALID_LABEL || !EDGE) atomicOr(&cold_args(kp)->flags[FLAG_RANGE], 1u);
-        return;
-    }
-    if (n == 0u) return;                  // the boundary at column 0: the run it closes belongs to the tile on the left
+// the ten sums of one run [c0, c0 + n) of row (al, bl), tile-local: every term < 2^32, every factor < 2^24
+template <bool MOM2>
+__device__ __forceinline__ RunSums run_sums(const uint32_t c0, const uint32_t n, const uint32_t al, const uint32_t bl) {
     const uint32_t t1 = __umul24(n, n - 1u);                                 // n (n - 1), even
     const uint32_t nc0 = __umul24(n, c0);
     const uint32_t sc = nc0 + (t1 >> 1);                                     // sum c over the run
@@ -228,16 +241,31 @@ __device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S,
     } else {
         L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
     }
+    return L;
+}
+
+// one run [s, k) of a row (tile-local a, b)
+template <bool MOM2, typename LDS>
+__device__ __forceinline__ void consume_scan_run(const SweepArgs* kp, LDS& S,
+                                                 const bool EDGE, uint32_t label, uint32_t s, uint32_t code, uint32_t lh,
+                                                 uint32_t lk) {
+    const uint32_t c0 = s, k = code & 1023u, bl = (code >> 10) & 15u, al = (code >> 14) & 63u;
+    const uint32_t n = k - c0;
+    if (label >= LABEL_LIMIT) {
+        // a real voxel the records cannot carry; INVALID_LABEL is the outside-the-volume filler of edge tiles only
+        if (label != INVALID_LABEL || !EDGE) atomicOr(&cold_args(kp)->flags[FLAG_RANGE], 1u);
+        return;
+    }
+    if (n == 0u) return;                  // the boundary at column 0: the run it closes belongs to the tile on the left
+    const RunSums L = run_sums<MOM2>(c0, n, al, bl);
     scan_label_add<MOM2, LDS, RunSums>(kp, S, label, L, al, al, bl, bl, c0, k - 1u, lh, lk);
 }
 
 // Drain both buffers of a wave completely, 64 records per pass, every lane busy but in the last pass.
-// CONS (the consumer wave's instance): `keep_in` says whether the last record stays behind (the producer has moved it to its
-// next buffer and seeded that buffer's carry slot already): nothing is written back into the buffer.
-template <bool ADJ, bool MOM2, bool CONS, typename LDS, typename WLDS>
+template <bool ADJ, bool MOM2, typename LDS, typename WLDS>
 __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S, WLDS& W,
                                               const bool EDGE, int lane, uint32_t& fcount, uint32_t& rcount,
-                                              const uint32_t lead_label, const bool may_keep, const uint32_t keep_in = 0u) {
+                                              const uint32_t lead_label, const bool may_keep) {
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (TA_ABLATE >= 1) { fcount = 0u; rcount = 0u; return; }
     if (ADJ) {
@@ -263,8 +291,8 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S, WLDS&
     // except when a row too big for the buffers is placed a lane range at a time (place_in_pieces).
     // (`may_keep`: only there.  Everywhere else a last record without a follower is complete as it is: the boundary with the
     //  tile on the left in a row that has no closing record.)
-    uint32_t keep = CONS ? keep_in : 0u;
-    if (!CONS && ADJ && may_keep && rcount) keep = (__builtin_amdgcn_readfirstlane((int)W.cqc[rcount]) & ROW_END) ? 0u : 1u;
+    uint32_t keep = 0u;
+    if (ADJ && may_keep && rcount) keep = (__builtin_amdgcn_readfirstlane((int)W.cqc[rcount]) & ROW_END) ? 0u : 1u;
     const uint32_t nrun = rcount - keep;
     for (uint32_t i = 0; i < nrun; i += 64u) {
         const uint32_t idx = i + (uint32_t)lane;
@@ -287,7 +315,7 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S, WLDS&
             consume_scan_run<MOM2, LDS>(kp, S, EDGE, label, s, code, lh, lk);
         }
     }
-    if (!CONS && rcount) {
+    if (rcount) {
         // carry: the record that follows (if it belongs to the same row) starts where the last consumed one ended; a record
         // that stays behind moves to the front
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -298,6 +326,250 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S, WLDS&
         }
         rcount = keep;
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+
+// ---- the hot drains: several groups of 64 records in flight at once -------------------------------------------------
+// drain_buffers above walks a buffer 64 (128) records at a time, and every group is a chain of dependent LDS round trips:
+// record -> home slot -> (compare-and-swap, next slot ...) -> counters.  Measured (profiles/r04_pmc_ablations.md): the drain
+// adds 17 % vector instructions and +0.34 ms to the sweep -- it waits.  Here a lane takes one record of EVERY group that is
+// drained: one round trip reads all of them, one more reads all their home slots, and each further probe round -- a
+// compare-and-swap where the slot read was EMPTY, the next slot where it held another key -- serves all lookups still
+// open in lockstep.  Same tables, same probing order, same spill rules as scan_pair_add / scan_label_add; sums and minima
+// commute, so the result is the same.
+// These drains run at the TOP of a plane -- where a wave holds nothing but the plane before, and the next plane's loads
+// are in flight anyway -- and take FULL groups only: what is left (at most 64 records) moves to the front of the buffer, so
+// no pass runs with idle lanes and a run record's follower is always in the buffer (no record has to stay behind).  The
+// drains inside a plane (a row that does not fit: drain_buffers) are the rare path.
+//
+// A lookup starts with a plain read of its home slot (most keys are there: same-address reads broadcast, they cost nothing).
+// What is still open after that goes through PROBE ROUNDS, and a round is ONE compare-and-swap of the EMPTY key by the wanted
+// one -- on the same slot when the read found it EMPTY, on the next slot when it held another key: what comes back is EMPTY
+// (the slot is ours now), the key (it is there) or another key (on to the next slot).  No read-then-CAS pair, no branch on
+// what was read: slot and state move by selects, the only divergent instruction is the masked compare-and-swap itself.
+// (Per-lane branches are what made the probe loops of drain_buffers slow: ~100 scalar / branch instructions a round.)
+#ifndef TA_PROBE_NORTN
+#define TA_PROBE_NORTN 1
+#endif
+template <typename LDS>
+__device__ __forceinline__ uint64_t pair_probe_issue(LDS& S, const bool pend, uint32_t& slot, const uint64_t k, const uint64_t key) {
+#if TA_PROBE_NORTN
+    // a compare-and-swap that returns nothing where the slot was EMPTY, then a plain read of the slot (the same one, or the
+    // next one where another key sits): LDS keeps a wave's operations in order, so the read sees what the swap left
+    if (pend && k == EMPTY_KEY) (void)atomicCAS((unsigned long long*)&S.pkeys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+    slot = (pend && k != EMPTY_KEY) ? ((slot + 1u) & (PSLOTS - 1)) : slot;
+    uint64_t r = k;
+    if (pend) r = S.pkeys[slot];
+    return r;
+#else
+    slot = (pend && k != EMPTY_KEY) ? ((slot + 1u) & (PSLOTS - 1)) : slot;
+    uint64_t r = k;
+    if (pend) r = atomicCAS((unsigned long long*)&S.pkeys[slot], (unsigned long long)EMPTY_KEY, (unsigned long long)key);
+    return r;
+#endif
+}
+template <typename LDS>
+__device__ __forceinline__ uint32_t label_probe_issue(LDS& S, const bool pend, uint32_t& slot, const uint32_t k, const uint32_t label) {
+#if TA_PROBE_NORTN
+    if (pend && k == INVALID_LABEL) (void)atomicCAS(&S.lkeys[slot], INVALID_LABEL, label);
+    slot = (pend && k != INVALID_LABEL) ? ((slot + 1u) & (LSLOTS - 1)) : slot;
+    uint32_t r = k;
+    if (pend) r = S.lkeys[slot];
+    return r;
+#else
+    slot = (pend && k != INVALID_LABEL) ? ((slot + 1u) & (LSLOTS - 1)) : slot;
+    uint32_t r = k;
+    if (pend) r = atomicCAS(&S.lkeys[slot], INVALID_LABEL, label);
+    return r;
+#endif
+}
+
+// TA_ABL_HOT (ablations of the hot drains, cumulative, results wrong by construction): 1 = nothing is added to the tables
+// (no count / sum / box atomics), 2 = ... and no probe rounds, 3 = ... and no home-slot reads, 4 = ... and no record reads
+#ifndef TA_ABL_HOT
+#define TA_ABL_HOT 0
+#endif
+// the first two groups (128 records) of a face buffer that holds at least that many
+template <typename LDS, typename WLDS>
+__device__ __forceinline__ void drain_face_groups(const SweepArgs* kp, LDS& S, WLDS& W, int lane, uint32_t& fcount) {
+    constexpr int NF = 2;
+    static_assert(FCAP >= 64 * NF && FCAP <= 64 * (NF + 1), "what is left after the groups moves to the front one record per lane");
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (TA_ABLATE >= 1) { fcount = 0u; return; }
+#ifdef TA_ABL_NOHOT
+    fcount = 0u; return;
+#endif
+    asm volatile("" : "+v"(lane));                // (keeps the addresses below out of the registers that live across the sweep)
+    uint2 rec[NF];
+#pragma unroll
+    for (int g = 0; g < NF; ++g) {
+        if (TA_ABL_HOT < 4) rec[g] = W.frec[lane + 64 * g];
+        else { rec[g].x = (uint32_t)lane * 2654435761u; rec[g].y = rec[g].x >> 7; asm volatile("" : "+v"(rec[g].x), "+v"(rec[g].y)); }
+    }
+    const uint32_t rem = fcount - 64u * NF;                               // <= 64
+    const uint2 tail = W.frec[(uint32_t)lane < rem ? 64u * NF + (uint32_t)lane : 0u];
+    uint32_t lo[NF], hi[NF], slot[NF];
+    uint64_t k[NF], key[NF];
+    bool live[NF], pend[NF];
+#pragma unroll
+    for (int g = 0; g < NF; ++g) {
+        const uint32_t v = rec[g].x, pv = rec[g].y & 0x3fffffffu;
+        // records that touch the outside-the-volume filler are dropped; a label the record words cannot carry (>= LABEL_LIMIT)
+        // raises FLAG_RANGE through the run record of its own voxel
+        lo[g] = v < pv ? v : pv; hi[g] = v < pv ? pv : v;
+        key[g] = ((uint64_t)lo[g] << 32) | hi[g];
+        live[g] = v < LABEL_LIMIT && pv < LABEL_LIMIT;
+        slot[g] = scan_pair_hash(lo[g], hi[g]);
+    }
+    // the home slot AND the one behind it (reads are cheap, a probe round is not: profiles/r04_ablation_ladder.txt): a key that
+    // another one has pushed off its home slot sits one slot further nine times in ten
+    uint64_t k1[NF];
+#pragma unroll
+    for (int g = 0; g < NF; ++g) {
+        if (TA_ABL_HOT < 3) { k[g] = S.pkeys[slot[g]]; k1[g] = S.pkeys[(slot[g] + 1u) & (PSLOTS - 1)]; }
+        else { k[g] = key[g]; k1[g] = key[g]; asm volatile("" :: "v"(slot[g])); }
+    }
+    if ((uint32_t)lane < rem) W.frec[lane] = tail;                         // (behind the reads of the same slots: LDS keeps a wave's order)
+#pragma unroll
+    for (int g = 0; g < NF; ++g) {
+        const bool home = k[g] == key[g] || k[g] == EMPTY_KEY;            // (it is there, or it goes there)
+        slot[g] = home ? slot[g] : ((slot[g] + 1u) & (PSLOTS - 1));
+        k[g] = home ? k[g] : k1[g];
+        pend[g] = live[g] && k[g] != key[g];
+    }
+    bool spill = false;
+#if !defined(TA_ABL_NOLOOP) && TA_ABL_HOT < 2
+#pragma nounroll
+    for (uint32_t round = 1u; __builtin_amdgcn_ballot_w64(pend[0] | pend[1]); ++round) {
+        static_assert(NF == 2, "two lookups per lane in lockstep");
+        if (round >= (uint32_t)PPROBE) { spill = true; break; }
+        const uint64_t r0 = pair_probe_issue(S, pend[0], slot[0], k[0], key[0]);
+        const uint64_t r1 = pair_probe_issue(S, pend[1], slot[1], k[1], key[1]);
+        // (a compare-and-swap that gave EMPTY back has put the key there; a plain read that gives EMPTY has found a free slot)
+        k[0] = (!TA_PROBE_NORTN && r0 == EMPTY_KEY) ? key[0] : r0; k[1] = (!TA_PROBE_NORTN && r1 == EMPTY_KEY) ? key[1] : r1;
+        pend[0] = pend[0] && k[0] != key[0]; pend[1] = pend[1] && k[1] != key[1];
+    }
+#endif
+#pragma unroll
+    for (int g = 0; g < NF; ++g) {
+        if (TA_ABL_HOT < 1) { if (live[g] && !pend[g]) pcnt_add(S, slot[g], rec[g].y >> 30); }
+        else asm volatile("" :: "v"(slot[g]), "s"(__builtin_amdgcn_ballot_w64(live[g] && !pend[g])));
+        if (spill) {          // (wave-uniform: the probe limit was reached with lookups still open)
+            if (pend[g]) { const SweepArgs* A = cold_args(kp); pair_spill_global(A->pairs, A->flags, lo[g], hi[g], rec[g].y >> 30, 1u); }
+        }
+    }
+    fcount = rem;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+}
+
+// the first 64 run records of a buffer that holds MORE than 64 (the follower of record 63 is there)
+template <bool MOM2, typename LDS, typename WLDS>
+__device__ __forceinline__ void drain_run_group(const SweepArgs* kp, LDS& S, WLDS& W, const bool EDGE, int lane, uint32_t& rcount,
+                                                const uint32_t lead_label) {
+    static_assert(RCAP <= 128, "what is left after one group moves to the front one record per lane");
+    constexpr int NW = MOM2 ? 6 : 2;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    if (TA_ABLATE >= 1) { rcount = 0u; return; }
+#ifdef TA_ABL_NOHOT
+    rcount = 0u; if (lane == 0) W.cqc[0] = NO_ROW; return;
+#endif
+    asm volatile("" : "+v"(lane));
+    uint32_t prev, code, ncode, label, nlabel;
+    if (TA_ABL_HOT < 4) {
+        prev = W.cqc[lane]; code = W.cqc[lane + 1]; ncode = W.cqc[lane + 2];
+        label = W.cql[lane + 1]; nlabel = W.cql[lane + 2];
+    } else {
+        prev = (uint32_t)lane * 3u; code = (uint32_t)lane * 3u + 2u; ncode = code + 3u; label = (uint32_t)lane >> 3; nlabel = label + 1u;
+        asm volatile("" : "+v"(prev), "+v"(code), "+v"(ncode), "+v"(label), "+v"(nlabel));
+    }
+    // what stays: records 64 .. rcount - 1 move to the front, the code of record 63 becomes the carry
+    const uint32_t rem = rcount - 64u;
+    const uint32_t tsrc = (uint32_t)lane < rem ? 65u + (uint32_t)lane : 0u;
+    const uint32_t tail_l = W.cql[tsrc], tail_c = W.cqc[tsrc], carry = W.cqc[64];
+    // the voxel right of the boundary: the closing label of the row's next record (it is in the buffer); none behind the
+    // record that closes the row; the leading label where the row has no closing record (see drain_buffers)
+    const uint32_t v = (code & ROW_END) ? INVALID_LABEL : (((code ^ ncode) & ROWID_MASK) == 0u) ? nlabel : lead_label;
+    const uint32_t plo = label < v ? label : v, phi = label < v ? v : label;
+    const uint64_t pkey = ((uint64_t)plo << 32) | phi;
+    const bool plive = v < LABEL_LIMIT && label < LABEL_LIMIT;
+    uint32_t pslot = scan_pair_hash(plo, phi);
+    const uint32_t c0 = ((prev ^ code) & ROWID_MASK) == 0u ? (prev & 1023u) : 0u, kk = code & 1023u;
+    // a real voxel the records cannot carry; INVALID_LABEL is the outside-the-volume filler of edge tiles only
+    const bool range = label >= LABEL_LIMIT && (label != INVALID_LABEL || !EDGE);
+    // (an empty run: the boundary at column 0 -- the run it closes belongs to the tile on the left)
+    const bool llive = label < LABEL_LIMIT && kk != c0;
+    uint32_t lslot = scan_label_hash(label);
+    uint64_t pk = pkey, pk1 = pkey;
+    uint32_t lk = label, lk1 = label;
+    if (TA_ABL_HOT < 3) {             // (the home slots and the ones behind them: see drain_face_groups)
+        pk = S.pkeys[pslot]; lk = S.lkeys[lslot];
+        pk1 = S.pkeys[(pslot + 1u) & (PSLOTS - 1)]; lk1 = S.lkeys[(lslot + 1u) & (LSLOTS - 1)];
+    } else asm volatile("" :: "v"(pslot), "v"(lslot));
+    if ((uint32_t)lane < rem) { W.cql[1 + lane] = tail_l; W.cqc[1 + lane] = tail_c; }
+    if (lane == 0) W.cqc[0] = carry;
+    if (__builtin_amdgcn_ballot_w64(range)) { if (range) atomicOr(&cold_args(kp)->flags[FLAG_RANGE], 1u); }
+    // the pair and the label lookup in lockstep
+    {
+        const bool phome = pk == pkey || pk == EMPTY_KEY, lhome = lk == label || lk == INVALID_LABEL;
+        pslot = phome ? pslot : ((pslot + 1u) & (PSLOTS - 1)); pk = phome ? pk : pk1;
+        lslot = lhome ? lslot : ((lslot + 1u) & (LSLOTS - 1)); lk = lhome ? lk : lk1;
+    }
+    bool ppend = plive && pk != pkey, lpend = llive && lk != label, spill = false;
+#if !defined(TA_ABL_NOLOOP) && TA_ABL_HOT < 2
+#pragma nounroll
+    for (uint32_t round = 1u; __builtin_amdgcn_ballot_w64(ppend | lpend); ++round) {
+        if (round >= (uint32_t)LPROBE) { spill = true; break; }          // (LPROBE <= PPROBE: both give up together)
+        const uint64_t rp = pair_probe_issue(S, ppend, pslot, pk, pkey);
+        const uint32_t rl = label_probe_issue(S, lpend, lslot, lk, label);
+        pk = (!TA_PROBE_NORTN && rp == EMPTY_KEY) ? pkey : rp; lk = (!TA_PROBE_NORTN && rl == INVALID_LABEL) ? label : rl;
+        ppend = ppend && pk != pkey; lpend = lpend && lk != label;
+    }
+#endif
+    // -- what the record carries, into the slots found.  The box is read before the sums are added (LDS operations of a
+    //    wave complete in order: a read behind six atomics would wait for them)
+    const uint32_t* boxr = &S.lbox[lslot * 8];
+    uint4 cur = {0u, 0u, 0u, 0xffffu};
+    uint2 cur2 = {0xffffu, 0xffffu};
+    if (TA_ABL_HOT < 1) {
+        cur = *reinterpret_cast<const uint4*>(boxr);              // min a,b,c | max a
+        cur2 = *reinterpret_cast<const uint2*>(boxr + 4);         // max b,c
+        if (plive && !ppend) pcnt_add(S, pslot, 2u);
+    } else asm volatile("" :: "v"(pslot), "s"(__builtin_amdgcn_ballot_w64(plive && !ppend)));
+    const uint32_t bl = (code >> 10) & 15u, al = (code >> 14) & 63u;
+    const RunSums L = run_sums<MOM2>(c0, kk - c0, al, bl);
+    if (TA_ABL_HOT >= 1) asm volatile("" :: "v"(L.n), "v"(L.sa), "v"(L.sb), "v"(L.sc), "v"(L.saa), "v"(L.sab), "v"(L.sac), "v"(L.sbb), "v"(L.sbc), "v"(L.scc), "v"(lslot), "s"(__builtin_amdgcn_ballot_w64(llive && !lpend)));
+    if (TA_ABL_HOT < 1 && llive && !lpend) {
+        unsigned long long* row = (unsigned long long*)&S.lsum[lslot * NW];
+        atomicAdd(row + 0, (unsigned long long)((uint64_t)L.n | ((uint64_t)L.sb << 32)));
+        atomicAdd(row + 1, (unsigned long long)((uint64_t)L.sa | ((uint64_t)L.sc << 32)));
+        if (MOM2) {
+            atomicAdd(row + 2, (unsigned long long)((uint64_t)L.saa | ((uint64_t)L.sab << 32)));
+            atomicAdd(row + 3, (unsigned long long)((uint64_t)L.sbb | ((uint64_t)L.sbc << 32)));
+            atomicAdd(row + (MOM2 ? 4 : 0), (unsigned long long)L.sac);
+            atomicAdd(row + (MOM2 ? 5 : 0), (unsigned long long)L.scc);
+        }
+        // bounding box: touched only when this run extends it (almost every run lies inside the box its label already has)
+        const bool grows = (al < cur.x) | (bl < cur.y) | (c0 < cur.z) | (al > cur.w) | (bl > cur2.x) | (kk - 1u > cur2.y);
+        if (grows) {
+            uint32_t* box = &S.lbox[lslot * 8];
+            atomicMin(box + 0, al); atomicMin(box + 1, bl); atomicMin(box + 2, c0);
+            atomicMax(box + 3, al); atomicMax(box + 4, bl); atomicMax(box + 5, kk - 1u);
+        }
+    }
+    if (spill) {              // (wave-uniform: the probe limit was reached with lookups still open)
+        if (ppend) { const SweepArgs* A = cold_args(kp); pair_spill_global(A->pairs, A->flags, plo, phi, 2u, 1u); }
+        if (lpend) {
+            const SweepArgs* A = cold_args(kp);
+            LocalSums Lc;
+            Lc.n = L.n; Lc.sa = L.sa; Lc.sb = L.sb; Lc.sc = L.sc; Lc.saa = L.saa; Lc.sab = L.sab;
+            Lc.sac = L.sac; Lc.sbb = L.sbb; Lc.sbc = L.sbc; Lc.scc = L.scc;
+            uint32_t bx[6];
+            bx[0] = al; bx[1] = bl; bx[2] = c0; bx[3] = al; bx[4] = bl; bx[5] = kk - 1u;
+            label_spill_global(A->sums, A->boxes, A->flags, A->max_label, label, &Lc, S.frame[0], S.frame[1], S.frame[2], bx);
+        }
+    }
+    rcount = rem;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
 }
 
@@ -378,19 +650,23 @@ __device__ __forceinline__ void unpack_strip(const u32x4& x, uint32_t (&dst)[VPL
 // column to the left.  PINB: 0 = plain guarded loads (volumes whose rows are not 16-byte aligned), else the first of the
 // hand-pinned registers the plane in flight lands in.  EDGE with PINB != 0 is the PADDED variant: interior-style loads from
 // clamped addresses, the positions outside the volume overwritten with the filler when the plane lands.
-// NBUF > 1: the wave only PRODUCES records; a buffer that cannot take the next row's records is handed over to the
-// workgroup's consumer wave and the wave goes on in its next buffer (it waits only when that one has not been drained yet).
-template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, int NBUF, typename LDS>
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, typename LDS>
 __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* kp, LDS& S, const int lane, const int w,
                                           const uint32_t c_tile0, const uint32_t b_tile0,
                                           const int32_t p_lo, const int32_t p_hi) {
     constexpr int TC = 64 * VPL;
-    constexpr bool HANDOVER = NBUF > 1;
     static_assert(TC <= 512, "the run code holds the end column in 10 bits");
     static_assert(FCAP >= RB * VPL && RCAP >= VPL + 1, "the records of one lane must fit a buffer");
-    static_assert(!HANDOVER || (ADJ && FCAP < 4096 && RCAP < 4096), "the hand-over word holds two 12-bit counts");
-    uint32_t bufsel = 0u;                                  // HANDOVER: which of the wave's NBUF buffers is being filled
-    auto* Wp = &S.wave[w * NBUF];
+    auto& W = S.wave[w];
+    // the hot drain sites take every record of a buffer at once (drain_faces_all / drain_runs_all); the rare ones -- a row too
+    // big for the buffers placed in pieces, the end of the tile -- keep the compact group-by-group drain_buffers
+#ifndef TA_DRAIN_ALL
+#define TA_DRAIN_ALL 1
+#endif
+#ifndef TA_FDRAIN
+#define TA_FDRAIN 128         // face records in the buffer from which the top-of-plane drain takes the full groups
+#endif
+    constexpr bool DRAIN_ALL = ADJ && TA_DRAIN_ALL && FCAP % 64 == 0 && RCAP % 64 == 0 && sizeof(T) == 4 && RB == 2 && !EDGE;
 
     const T* vol = reinterpret_cast<const T*>(A.vol);
     const int64_t n1 = A.n1, n2 = A.n2, plane = n1 * n2;
@@ -498,13 +774,13 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #ifdef TA_STAMPS
     uint64_t tk_cmp = 0, tk_emit = 0, tk_drain = 0, tk_adv = 0, tk_land = 0, tk_evrows = 0, tk_drains = 0;
 #endif
-    if (lane == 0) Wp->cqc[0] = NO_ROW;
+    if (lane == 0) W.cqc[0] = NO_ROW;
     // LDS byte offsets of the wave's buffers (the low half of a flat LDS address is the LDS offset)
-    uint32_t fbase = (uint32_t)(uintptr_t)&Wp->frec[0];
-    uint32_t rbase = (uint32_t)(uintptr_t)&Wp->cql[1];
+    const uint32_t fbase = (uint32_t)(uintptr_t)&W.frec[0];
+    const uint32_t rbase = (uint32_t)(uintptr_t)&W.cql[1];
     constexpr uint32_t RSTRIDE = (RCAP + 2) * 4u;         // bytes between the two run arrays
-    uint32_t ftrash = (uint32_t)(uintptr_t)&Wp->frec[FTRASH];   // where the stores of compares that did not fire go
-    uint32_t rtrash = (uint32_t)(uintptr_t)&Wp->cql[RTRASH];
+    const uint32_t ftrash = (uint32_t)(uintptr_t)&W.frec[FTRASH];   // where the stores of compares that did not fire go
+    const uint32_t rtrash = (uint32_t)(uintptr_t)&W.cql[RTRASH];
 
     // Leading rows of the tile that are one label (the label of its first voxel) from end to end are not records:
     // they are counted and added in closed form at the end -- that is the whole cost of background.
@@ -518,36 +794,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #ifdef TA_RECCOUNT
         if (lane == 0) { atomicAdd(&cold_args(kp)->flags[8], fcount); atomicAdd(&cold_args(kp)->flags[9], rcount); atomicAdd(&cold_args(kp)->flags[10], 1u); }
 #endif
-        if constexpr (!HANDOVER) {
-            drain_buffers<ADJ, MOM2, false, LDS>(kp, S, *Wp, EDGE, lane, fcount, rcount, first_label, may_keep);
-        } else {
-            // Hand the buffer over to the consumer wave and go on in the next one.  A boundary record whose follower has not
-            // been placed yet (may_keep) moves to the front of the next buffer; the consumer is told to leave it alone.
-            if (fcount == 0u && rcount == 0u) return;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-            uint32_t keep = 0u;
-            if (may_keep && rcount) keep = (__builtin_amdgcn_readfirstlane((int)Wp->cqc[rcount]) & ROW_END) ? 0u : 1u;
-            const uint32_t nrun = rcount - keep;
-            const uint32_t nsel = bufsel + 1u == (uint32_t)NBUF ? 0u : bufsel + 1u;
-            auto* Wn = &S.wave[w * NBUF + (int)nsel];
-            uint32_t* const ctl_next = &S.ctl[w * NBUF + (int)nsel];
-            // (the next buffer is free once the consumer has written 0 over its word; the load is wave-uniform)
-            while (__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctl_next, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != 0)
-                __builtin_amdgcn_s_sleep(2);
-            if (lane == 0) {
-                // carry: the record that follows (if it belongs to the same row) starts where the last consumed one ended
-                const uint32_t carry = Wp->cqc[nrun];
-                if (keep) { const uint32_t kl = Wp->cql[rcount], kc = Wp->cqc[rcount]; Wn->cql[1] = kl; Wn->cqc[1] = kc; }
-                Wn->cqc[0] = carry;
-                __hip_atomic_store(&S.ctl[w * NBUF + (int)bufsel], CTL_FULL | (keep ? CTL_KEEP : 0u) | fcount | (nrun << 12),
-                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            bufsel = nsel; Wp = Wn;
-            fbase = (uint32_t)(uintptr_t)&Wp->frec[0]; rbase = (uint32_t)(uintptr_t)&Wp->cql[1];
-            ftrash = (uint32_t)(uintptr_t)&Wp->frec[FTRASH]; rtrash = (uint32_t)(uintptr_t)&Wp->cql[RTRASH];
-            fcount = 0u; rcount = keep;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        }
+        drain_buffers<ADJ, MOM2, LDS>(kp, S, W, EDGE, lane, fcount, rcount, first_label, may_keep);
 #ifdef TA_STAMPS
         tk_drain += __builtin_amdgcn_s_memtime() - td0; tk_drains += 1;
 #endif
@@ -686,10 +933,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             }
             leftv = nxt_leftv;
         }
-        if (p == p_lo) {
-            first_label = __builtin_amdgcn_readfirstlane(cur[0][0]);
-            if (HANDOVER && lane == 0) S.lead[w] = first_label;          // (published with the first buffer handed over)
-        }
+        if (p == p_lo) first_label = __builtin_amdgcn_readfirstlane(cur[0][0]);
         const bool with_plane_faces = ADJ && (p > p_lo || has_prev);
         const uint32_t cf_plane = with_plane_faces ? count_plane_faces() : 0u;
 #ifdef TA_STAMPS
@@ -787,6 +1031,15 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     //      that kernel is bound by its instructions per voxel, not by the bytes it has in flight.)
     {
         for (int32_t p = p_lo; p < p_hi; ++p) {
+            if constexpr (DRAIN_ALL) {
+                // the hot drains: between two planes a wave holds nothing but the plane before (and the next one is in flight)
+#ifdef TA_RECCOUNT
+                if (lane == 0 && fcount >= (uint32_t)TA_FDRAIN) atomicAdd(&cold_args(kp)->flags[11], 128u);
+                if (lane == 0 && rcount > 64u) atomicAdd(&cold_args(kp)->flags[12], 64u);
+#endif
+                if (fcount >= (uint32_t)TA_FDRAIN) drain_face_groups<LDS>(kp, S, W, lane, fcount);
+                if (rcount > 64u) drain_run_group<MOM2, LDS>(kp, S, W, EDGE, lane, rcount, first_label);
+            }
             if constexpr (PINB != 0) {
 #ifdef TA_STAMPS
                 const uint64_t t4 = TA_T();
@@ -812,8 +1065,6 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 
     // ---- end of tile: drain the buffers, then the leading one-label rows in one closed form
     drain(false);
-    if (HANDOVER && lane == 0)         // no more buffers will come from this wave
-        __hip_atomic_store(&S.ctl[WAVES * NBUF + w], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (__builtin_amdgcn_ballot_w64(bad)) { if (lane == 0) atomicOr(&cold_args(kp)->flags[FLAG_RANGE], 1u); }
     if (lane == 0 && nlead != 0u && first_label != INVALID_LABEL) {
         // rows in (plane, row) order: P full planes of RB rows, then R rows of plane P
@@ -841,42 +1092,6 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     }
 }
 
-// The consumer wave of a workgroup whose producers hand their buffers over (NBUF > 1): it polls the control words -- lane i
-// reads word i: one LDS read per poll -- drains the full buffers round-robin and leaves once every producer has said that no
-// more will come and a later poll has found no full buffer (a producer publishes its last buffer BEFORE that word).
-template <bool MOM2, int NBUF, typename LDS>
-__device__ __forceinline__ void consumer_loop(const SweepArgs* kp, LDS& S, const int lane) {
-    constexpr uint32_t NB = WAVES * NBUF;
-    uint32_t rot = 0u;
-    bool confirmed = false;
-    for (;;) {
-        uint32_t word = 0u;
-        if (lane < (int)(NB + WAVES)) word = __hip_atomic_load(&S.ctl[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const uint64_t nz = __builtin_amdgcn_ballot_w64(word != 0u);
-        const uint32_t full = (uint32_t)nz & ((1u << NB) - 1u);
-        if (full) {
-            const uint32_t later = full >> rot << rot;                      // the full buffers at or after `rot`
-            const uint32_t b = (uint32_t)__builtin_ctz(later ? later : full);
-            const uint32_t cw = (uint32_t)__builtin_amdgcn_readlane((int)word, (int)b);
-            const uint32_t keep = (cw & CTL_KEEP) ? 1u : 0u;
-            uint32_t fcount = cw & 0xfffu, rcount = ((cw >> 12) & 0xfffu) + keep;
-            const uint32_t lead = (uint32_t)__builtin_amdgcn_readfirstlane((int)S.lead[b / (uint32_t)NBUF]);
-            drain_buffers<true, MOM2, true, LDS>(kp, S, S.wave[b], false, lane, fcount, rcount, lead, false, keep);
-            if (lane == 0) __hip_atomic_store(&S.ctl[b], 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            rot = b + 1u == NB ? 0u : b + 1u;
-            confirmed = false;
-            continue;
-        }
-        if ((uint32_t)(nz >> NB) == (1u << WAVES) - 1u) {
-            if (confirmed) break;
-            confirmed = true;
-            continue;
-        }
-        __builtin_amdgcn_s_sleep(4);
-    }
-}
-
 // Tiles of a volume: `fc` x `fb` full tiles per plane band go to the interior kernel (hand-issued 16-byte loads, no
 // bounds); the partial tiles of the last tile column / tile row go to the PADDED kernel (the same loads from clamped
 // addresses, filler written over what lies outside) when 16-byte loads are allowed (SweepArgs::vec_ok), else everything
@@ -898,21 +1113,51 @@ static ScanSplit scan_split(const SweepArgs& a, int itemsize) {
     return s;
 }
 
-template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, int NBUF = 1>
+#ifndef TA_PERSIST_SINGLE_QUEUE
+#define TA_PERSIST_SINGLE_QUEUE 0
+#endif
+// The next tile of a persistent workgroup: from the list of its own XCD (workgroups are dealt round-robin over the 8 XCDs;
+// an XCD's list is every eighth CHUNK of TA_XCD_CHUNK consecutive tiles -- neighbours along axes 2 and 1, so that the halo
+// row a tile reads is the row its neighbour on the same XCD / L2 reads at about the same time -- plus its share of the last,
+// partial group of chunks), then from the other XCDs' lists.  Speed only: any workgroup may take any tile.
+__device__ __forceinline__ uint32_t claim_tile(uint32_t* queues, const uint32_t xcd, const uint32_t ntiles) {
+    constexpr uint32_t G = TA_XCD_CHUNK > 0 ? TA_XCD_CHUNK : 1;
+    const uint32_t per = (ntiles / (8u * G)) * G, full = per * 8u;          // tiles of the whole groups of chunks: per XCD, in all
+#if TA_PERSIST_SINGLE_QUEUE      // (experiment: one queue, tiles in plain order)
+    {
+        const uint32_t j = __hip_atomic_fetch_add(&queues[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return j < ntiles ? j : NO_TILE;
+    }
+#endif
+#pragma nounroll
+    for (uint32_t s = 0; s < 8u; ++s) {
+        const uint32_t x = (xcd + s) & 7u;
+        const uint32_t nx = per + (ntiles - full + 7u - x) / 8u;            // ... plus every eighth tile of the rest
+        // (an empty list is seen by a plain load: at the end every workgroup walks all eight lists, and a thousand
+        //  read-modify-writes of one word take their time)
+        if (__hip_atomic_load(&queues[x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= nx) continue;
+        const uint32_t j = __hip_atomic_fetch_add(&queues[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (j < nx) return j < per ? ((j / G) * 8u + x) * G + (j % G) : full + (j - per) * 8u + x;
+    }
+    return NO_TILE;
+}
+
+// PERSIST: the workgroup walks tiles until the queues are empty: its tables are emptied by the flush itself, the flush's global
+// atomics are left in flight while the next tile starts, and no workgroup has to be launched (and waited out) per tile.
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, bool PERSIST = false>
 __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanSplit& sp, const uint32_t wg0) {
     constexpr int NW = MOM2 ? 6 : 2;
     constexpr int TC = 64 * VPL, TB = WAVES * RB;
-    constexpr int NT = (WAVES + (NBUF > 1 ? 1 : 0)) * 64;          // threads: the producers (+ the consumer wave)
     static_assert(TB <= 16 && TC <= 512, "packed LDS moment words assume <= 16 rows x 512 columns per tile");
-    using LDS = ScanLds<NW, ADJ, NBUF>;
-    static_assert(NBUF == 1 || sizeof(LDS) <= 40960, "four workgroups with a consumer wave must fit the 160 KB of a CU");
+    static_assert(!PERSIST || !EDGE, "the persistent kernel walks the full tiles");
+    using LDS = ScanLds<NW, ADJ>;
     __shared__ LDS S;
     // the arguments only the cold paths need are re-read from the kernarg segment there (see cold_args)
     const SweepArgs* kp = kernarg_args(A);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    for (int i = tid; i < LSLOTS; i += NT) {
+    for (int i = tid; i < LSLOTS; i += WAVES * 64) {
         S.lkeys[i] = INVALID_LABEL;
 #pragma unroll
         for (int k = 0; k < NW; ++k) S.lsum[i * NW + k] = 0ull;
@@ -920,59 +1165,80 @@ __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanS
         S.lbox[i * 8 + 3] = 0u; S.lbox[i * 8 + 4] = 0u; S.lbox[i * 8 + 5] = 0u;
     }
     if (ADJ) {
-        for (int i = tid; i < PSLOTS; i += NT) {
+        for (int i = tid; i < PSLOTS; i += WAVES * 64) {
             S.pkeys[i] = EMPTY_KEY;
+#if TA_PCNT64
             S.pcnt[i] = 0ull;
-        }
-    }
-    if (NBUF > 1) {
-        if (tid < WAVES * NBUF + WAVES) S.ctl[tid] = 0u;
-    }
-    const uint32_t wg = wg0 + blockIdx.x;
-    if (TA_HOT_ADJ || !ADJ) hot_row_init(A, tid, wg);
-
-    uint32_t t = blockIdx.x, tc, tb, band;
-#if TA_XCD_CHUNK > 0
-    // Workgroups are dealt round-robin over the 8 XCDs (speed only, never correctness: placement is not promised).
-    // Give each XCD CHUNKS of consecutive tiles -- neighbours along axes 2 and 1 -- so that the halo row a tile reads is
-    // the row its neighbour on the same XCD reads at about the same time (one HBM fetch, one L2), while chunks stay
-    // small enough that tissue and background tiles still spread evenly over the XCDs.
-    if (!EDGE) {
-        constexpr uint32_t G = TA_XCD_CHUNK;
-        const uint32_t full = (gridDim.x / (8u * G)) * (8u * G);
-        if (t < full) {
-            const uint32_t xcd = t % 8u, k = t / 8u;
-            t = ((k / G) * 8u + xcd) * G + (k % G);
-        }
-    }
+#else
+            S.pcnt[i * 3 + 0] = 0u; S.pcnt[i * 3 + 1] = 0u; S.pcnt[i * 3 + 2] = 0u;
 #endif
-    if (!EDGE) {
-        tc = t % sp.fc; t /= sp.fc; tb = t % sp.fb; band = t / sp.fb;
-    } else {
-        const uint32_t per_band = sp.tiles_c * sp.tiles_b - sp.fc * sp.fb, strip = (sp.tiles_c - sp.fc) * sp.tiles_b;
-        band = t / per_band; t -= band * per_band;
-        if (t < strip) { tc = sp.fc + t % (sp.tiles_c - sp.fc); tb = t / (sp.tiles_c - sp.fc); }       // the last tile column(s)
-        else { t -= strip; tc = t % sp.fc; tb = sp.fb + t / sp.fc; }                                    // the last tile row(s)
+        }
     }
-    const uint32_t c_tile0 = tc * TC, b_tile0 = tb * TB;
-    const int32_t p_lo = A.first_owned + (int32_t)band * A.tile_planes;
-    int32_t p_hi = p_lo + A.tile_planes;
-    if (p_hi > (int32_t)A.n0) p_hi = (int32_t)A.n0;
-    const uint64_t A0 = (uint64_t)(A.a_origin + (p_lo - A.first_owned));
-    if (tid == 0) { S.frame[0] = (uint32_t)A0; S.frame[1] = b_tile0; S.frame[2] = c_tile0; }
-    __syncthreads();
+    uint32_t tile = blockIdx.x;
+    if (PERSIST) {
+        if (tid == 0) S.frame[3] = claim_tile(cold_args(kp)->flags + QUEUE_WORD, blockIdx.x & 7u, sp.fc * sp.fb * sp.nbands);
+        __syncthreads();
+        tile = S.frame[3];
+    }
+    for (;;) {
+        if (PERSIST && tile == NO_TILE) break;
+        uint32_t t = tile, tc, tb, band;
+#if TA_XCD_CHUNK > 0
+        // Workgroups are dealt round-robin over the 8 XCDs (speed only, never correctness: placement is not promised).
+        // Give each XCD CHUNKS of consecutive tiles -- neighbours along axes 2 and 1 -- so that the halo row a tile reads is
+        // the row its neighbour on the same XCD reads at about the same time (one HBM fetch, one L2), while chunks stay
+        // small enough that tissue and background tiles still spread evenly over the XCDs.  (PERSIST: claim_tile does it.)
+        if (!EDGE && !PERSIST) {
+            constexpr uint32_t G = TA_XCD_CHUNK;
+            const uint32_t full = (gridDim.x / (8u * G)) * (8u * G);
+            if (t < full) {
+                const uint32_t xcd = t % 8u, k = t / 8u;
+                t = ((k / G) * 8u + xcd) * G + (k % G);
+            }
+        }
+#endif
+        if (!EDGE) {
+            tc = t % sp.fc; t /= sp.fc; tb = t % sp.fb; band = t / sp.fb;
+        } else {
+            const uint32_t per_band = sp.tiles_c * sp.tiles_b - sp.fc * sp.fb, strip = (sp.tiles_c - sp.fc) * sp.tiles_b;
+            band = t / per_band; t -= band * per_band;
+            if (t < strip) { tc = sp.fc + t % (sp.tiles_c - sp.fc); tb = t / (sp.tiles_c - sp.fc); }       // the last tile column(s)
+            else { t -= strip; tc = t % sp.fc; tb = sp.fb + t / sp.fc; }                                    // the last tile row(s)
+        }
+        // (the private hot-label row of a tile: numbered by the tile, whichever workgroup walks it)
+        if (TA_HOT_ADJ || !ADJ) hot_row_init(A, tid, wg0 + tile);
+        const uint32_t c_tile0 = tc * TC, b_tile0 = tb * TB;
+        const int32_t p_lo = A.first_owned + (int32_t)band * A.tile_planes;
+        int32_t p_hi = p_lo + A.tile_planes;
+        if (p_hi > (int32_t)A.n0) p_hi = (int32_t)A.n0;
+        const uint64_t A0 = (uint64_t)(A.a_origin + (p_lo - A.first_owned));
+        if (tid == 0) { S.frame[0] = (uint32_t)A0; S.frame[1] = b_tile0; S.frame[2] = c_tile0; }
+        __syncthreads();
 
-    if (p_lo < p_hi) {
-        if (NBUF > 1 && w == WAVES) consumer_loop<MOM2, NBUF>(kp, S, lane);
-        else wave_scan<T, VPL, RB, ADJ, MOM2, EDGE, PINB, NBUF>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
+        if (p_lo < p_hi)
+            wave_scan<T, VPL, RB, ADJ, MOM2, EDGE, PINB>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
+        __syncthreads();
+        // (everything the flush needs is re-read -- arguments from the kernarg segment, the tile origin from LDS --
+        //  rather than kept in scarce SGPRs across the sweep)
+        const SweepArgs& Ac = *cold_args(kp);
+        const uint32_t wg_ = reinterpret_cast<const uint32_t*>(&Ac + 1)[sizeof(ScanSplit) / 4] + tile;     // wg0 + tile
+        uint32_t next = NO_TILE;
+        if (PERSIST && tid == 0) {          // (asked for before the flush, needed after it)
+            const ScanSplit& spc = *reinterpret_cast<const ScanSplit*>(&Ac + 1);
+            next = claim_tile(Ac.flags + QUEUE_WORD, blockIdx.x & 7u, spc.fc * spc.fb * spc.nbands);
+        }
+#ifndef TA_ABL_NOFLUSH
+        flush_tables<NW, ADJ, MOM2, (TA_HOT_ADJ || !ADJ), LDS, WAVES * 64, PERSIST>(Ac, S, threadIdx.x, (uint64_t)S.frame[0], (uint64_t)S.frame[1], (uint64_t)S.frame[2],
+                                          (TA_HOT_ADJ || !ADJ) ? hot_label_of<T>(Ac) : 0u, wg_);
+#else
+        if (wg_ == 0xffffffffu) S.frame[3] = 1;
+#endif
+        if (!PERSIST) break;
+        __syncthreads();                     // (the tile origin has been read by every thread's flush)
+        if (tid == 0) S.frame[3] = next;
+        __syncthreads();
+        tile = S.frame[3];
     }
-    __syncthreads();
-    // (everything the flush needs is re-read -- arguments from the kernarg segment, the tile origin from LDS --
-    //  rather than kept in scarce SGPRs across the sweep)
-    const SweepArgs& Ac = *cold_args(kp);
-    const uint32_t wg_ = reinterpret_cast<const uint32_t*>(&Ac + 1)[sizeof(ScanSplit) / 4] + blockIdx.x;     // wg0 + block
-    flush_tables<NW, ADJ, MOM2, (TA_HOT_ADJ || !ADJ), LDS, NT>(Ac, S, threadIdx.x, (uint64_t)S.frame[0], (uint64_t)S.frame[1], (uint64_t)S.frame[2],
-                                      (TA_HOT_ADJ || !ADJ) ? hot_label_of<T>(Ac) : 0u, wg_);
 }
 
 // (several entry points only because the VGPR budget is an attribute and must be a literal)
@@ -980,15 +1246,20 @@ template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ))) scan_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
     scan_kernel_body<T, VPL, RB, true, MOM2, EDGE, EDGE ? 0 : TA_PIN_ADJ>(A, sp, wg0);
 }
-// the full tiles of a uint32 volume with adjacency: two rows per wave, five waves per SIMD
-#ifndef TA_NBUF
-#define TA_NBUF 2         // record buffers per producer wave of the kernel with a consumer wave (1 = no consumer wave)
+// the full tiles of a uint32 volume with adjacency: two rows per wave, five waves per SIMD.
+// TA_PERSIST (measured, NOT adopted: profiles/r04_NOTES.md): 1280 persistent workgroups that take tiles from per-XCD queues and
+// leave the flush's global atomics in flight.  C4 1.30 ms against 1.07 ms with a workgroup per tile -- the same instructions
+// (SQ_INSTS_* equal to 1 %), but the waves are parked twice as long (SQ_WAIT_ANY 2.3e9 against 1.1e9 quad-cycles).
+#ifndef TA_PERSIST
+#define TA_PERSIST 0
 #endif
-constexpr int TWO_ROWS_THREADS = (WAVES + (TA_NBUF > 1 ? 1 : 0)) * 64;
+#ifndef TA_PERSIST_WGS
+#define TA_PERSIST_WGS (256 * 5)       // what the chip holds at five workgroups per CU (fewer tiles: one workgroup each)
+#endif
 template <typename T, int VPL, int RB, bool MOM2>
-__global__ void __launch_bounds__(TWO_ROWS_THREADS) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ2))) scan_two_rows_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ2))) scan_two_rows_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
     static_assert(RB == 2 && sizeof(T) == 4, "the 13-register landing zone holds two rows of a uint32 volume");
-    scan_kernel_body<T, VPL, RB, true, MOM2, false, TA_PIN_ADJ2, TA_NBUF>(A, sp, wg0);
+    scan_kernel_body<T, VPL, RB, true, MOM2, false, TA_PIN_ADJ2, TA_PERSIST != 0>(A, sp, wg0);
 }
 template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_MOM))) scan_noadj_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
@@ -1017,7 +1288,8 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_star
     hipEvent_t ed0 = n_in ? nullptr : ev_start, ed1 = ev_stop;              // edge launch
     if constexpr (ADJ) {
         if constexpr (sizeof(T) == 4 && RB == 2) {
-            if (n_in) hipExtLaunchKernelGGL((scan_two_rows_kernel<T, VPL, RB, MOM2>), dim3(n_in), dim3(TWO_ROWS_THREADS), 0, s, in0, in1, 0, a, sp, 0u);
+            const uint32_t grid = TA_PERSIST ? (n_in < (uint32_t)TA_PERSIST_WGS ? n_in : (uint32_t)TA_PERSIST_WGS) : n_in;
+            if (n_in) hipExtLaunchKernelGGL((scan_two_rows_kernel<T, VPL, RB, MOM2>), dim3(grid), block, 0, s, in0, in1, 0, a, sp, 0u);
         } else {
             if (n_in) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
         }

@@ -132,7 +132,7 @@ struct ta_ctx {
 
 namespace {
 
-constexpr int SMALL_WORDS = ta::NFLAGS + 4;   // flags, cursor, max label, parked hot-row pointer (2 words)
+constexpr int SMALL_WORDS = ta::SMALL_WORDS_DEV;   // flags, cursor, max label, parked hot-row pointer (2 words), tile queues (8)
 
 uint32_t* flags_dev(ta_ctx* c) { return (uint32_t*)c->small.p; }
 uint32_t* cursor_dev(ta_ctx* c) { return (uint32_t*)c->small.p + ta::NFLAGS; }

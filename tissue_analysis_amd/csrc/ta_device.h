@@ -49,6 +49,11 @@ struct SweepArgs {
 // init_kernel and fetched with a scalar load where it is needed.
 constexpr int HOTW = 16;             // u64 words of a hot row: sums u64[NSUM] | boxes i32[NBOX] | padding
 constexpr int HOT_PTR_WORD = NFLAGS + 2;   // uint32 index into the flags buffer, 8-byte aligned
+// Tile queues of the persistent sweep kernel (one counter per XCD, zeroed by init_kernel before every sweep): a workgroup
+// takes the next tile of its own XCD's list -- consecutive tiles stay on one XCD's L2 -- and helps the others when it is empty.
+constexpr int QUEUE_WORD = NFLAGS + 4, NQUEUES = 8;
+constexpr int SMALL_WORDS_DEV = NFLAGS + 4 + NQUEUES;     // flags | pair cursor | max label | hot-row pointer (2) | tile queues
+constexpr uint32_t NO_TILE = 0xFFFFFFFFu;
 
 __device__ __forceinline__ uint32_t hash_u32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;

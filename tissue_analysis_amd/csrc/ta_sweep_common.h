@@ -29,8 +29,12 @@ constexpr int LPROBE = 16;        // max probes before spilling to global atomic
 constexpr int PPROBE = 32;
 constexpr int MAX_TILE_PLANES = 64;
 constexpr uint32_t LABEL_LIMIT = 1u << 28;    // max_label < 2^28: the two top bits of a record word are free
-// a pair's three per-axis face counts of ONE tile share a u64 LDS word, 21 bits each (a tile holds at most
-// 16 rows x 512 columns x 64 planes = 2^19 voxels, so a field cannot carry into the next): one table of 8 bytes per slot
+// TA_PCNT64 (measured, not adopted): a pair's three per-axis face counts of ONE tile in a u64 LDS word, 21 bits each (a tile
+// holds at most 16 rows x 512 columns x 64 planes = 2^19 voxels, so a field cannot carry into the next): 8 bytes per slot
+// instead of 12, but every LDS atomic on it costs twice the cycles of a u32 one
+#ifndef TA_PCNT64
+#define TA_PCNT64 0
+#endif
 constexpr int PCNT_BITS = 21;
 constexpr uint64_t PCNT_MASK = (1ull << PCNT_BITS) - 1ull;
 
@@ -120,7 +124,8 @@ __device__ __forceinline__ void hot_row_init(const SweepArgs& A, const int tid, 
 __device__ __forceinline__ void hot_row_init(const SweepArgs& A, const int tid) { hot_row_init(A, tid, blockIdx.x); }
 
 // HOT = false compiles the hot-row path out (the naive cross-check kernel's rows; the sweep uses it for every mask).
-template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS, int NT = WAVES * 64>
+// RESET: every slot that held something is emptied again as it is read (the persistent kernel goes on with the next tile).
+template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS, int NT = WAVES * 64, bool RESET = false>
 __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const int tid, const uint64_t A0,
                                              const uint64_t B0, const uint64_t C0, const uint32_t hot,
                                              const uint32_t wg) {
@@ -128,7 +133,17 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
     for (int i = tid; i < LSLOTS; i += NT) {
         const uint32_t label = S.lkeys[i];
         if (label == INVALID_LABEL) continue;
-        if (label > A.max_label) { atomicOr(&A.flags[FLAG_RANGE], 1u); continue; }
+        if (RESET) S.lkeys[i] = INVALID_LABEL;
+        if (label > A.max_label) {
+            atomicOr(&A.flags[FLAG_RANGE], 1u);
+            if (RESET) {
+#pragma unroll
+                for (int k = 0; k < NW; ++k) S.lsum[i * NW + k] = 0ull;
+                S.lbox[i * 8 + 0] = 0xFFFFFFFFu; S.lbox[i * 8 + 1] = 0xFFFFFFFFu; S.lbox[i * 8 + 2] = 0xFFFFFFFFu;
+                S.lbox[i * 8 + 3] = 0u; S.lbox[i * 8 + 4] = 0u; S.lbox[i * 8 + 5] = 0u;
+            }
+            continue;
+        }
         const uint64_t w0 = S.lsum[i * NW + 0], w1 = S.lsum[i * NW + 1];
         LocalSums L;
         L.n = w0 & 0xffffffffull; L.sb = w0 >> 32; L.sa = w1 & 0xffffffffull; L.sc = w1 >> 32;
@@ -152,14 +167,33 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
         atomicMin(box + 0, (int32_t)(A0 + S.lbox[i * 8 + 0])); atomicMin(box + 3, -(int32_t)(A0 + S.lbox[i * 8 + 3]));
         atomicMin(box + 1, (int32_t)(B0 + S.lbox[i * 8 + 1])); atomicMin(box + 4, -(int32_t)(B0 + S.lbox[i * 8 + 4]));
         atomicMin(box + 2, (int32_t)(C0 + S.lbox[i * 8 + 2])); atomicMin(box + 5, -(int32_t)(C0 + S.lbox[i * 8 + 5]));
+        if (RESET) {
+#pragma unroll
+            for (int k = 0; k < NW; ++k) S.lsum[i * NW + k] = 0ull;
+            S.lbox[i * 8 + 0] = 0xFFFFFFFFu; S.lbox[i * 8 + 1] = 0xFFFFFFFFu; S.lbox[i * 8 + 2] = 0xFFFFFFFFu;
+            S.lbox[i * 8 + 3] = 0u; S.lbox[i * 8 + 4] = 0u; S.lbox[i * 8 + 5] = 0u;
+        }
     }
     if (ADJ) {
         for (int i = tid; i < PSLOTS; i += NT) {
             const uint64_t key = S.pkeys[i];
             if (key == EMPTY_KEY) continue;
+#if TA_PCNT64
             const uint64_t c = S.pcnt[i];
             pair_add_global(A.pairs, (uint32_t)(key >> 32), (uint32_t)key, c & PCNT_MASK,
                             (c >> PCNT_BITS) & PCNT_MASK, c >> (2 * PCNT_BITS), A.flags);
+#else
+            pair_add_global(A.pairs, (uint32_t)(key >> 32), (uint32_t)key, S.pcnt[i * 3 + 0],
+                            S.pcnt[i * 3 + 1], S.pcnt[i * 3 + 2], A.flags);
+#endif
+            if (RESET) {
+                S.pkeys[i] = EMPTY_KEY;
+#if TA_PCNT64
+                S.pcnt[i] = 0ull;
+#else
+                S.pcnt[i * 3 + 0] = 0u; S.pcnt[i * 3 + 1] = 0u; S.pcnt[i * 3 + 2] = 0u;
+#endif
+            }
         }
     }
 }
