@@ -65,6 +65,30 @@ __device__ __forceinline__ uint32_t hash_pair(uint32_t lo, uint32_t hi) {
 
 // Insert/accumulate one pair into the device-global table.  Slots only ever go EMPTY -> key
 // inside a launch, so a stale EMPTY read is repaired by the CAS and a non-EMPTY read is final.
+// (`h`, `k`: the pair's home slot and the key a caller has read from it already -- it issues that read early, with other
+//  work in between, so that the first global round trip of the probe is not waited for; see flush_tables.)
+__device__ __forceinline__ void pair_add_global_from(const PairTable& pt, uint32_t lo, uint32_t hi, uint64_t f0, uint64_t f1, uint64_t f2,
+                                                     uint32_t* flags, uint32_t h, uint64_t k) {
+    const uint64_t key = ((uint64_t)lo << 32) | hi;
+    for (uint32_t probe = 0; probe < 512u; ++probe) {
+        if (k == EMPTY_KEY) {
+            k = atomicCAS((unsigned long long*)&pt.keys[h], (unsigned long long)EMPTY_KEY,
+                          (unsigned long long)key);
+            if (k == EMPTY_KEY) k = key;
+        }
+        if (k == key) {
+            unsigned long long* f = (unsigned long long*)&pt.faces[3ull * h];
+            if (f0) atomicAdd(f + 0, (unsigned long long)f0);
+            if (f1) atomicAdd(f + 1, (unsigned long long)f1);
+            if (f2) atomicAdd(f + 2, (unsigned long long)f2);
+            return;
+        }
+        h = (h + 1) & pt.mask;
+        k = __hip_atomic_load(&pt.keys[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    atomicOr(&flags[FLAG_PAIR_OVERFLOW], 1u);
+}
+
 __device__ inline void pair_add_global(const PairTable& pt, uint32_t lo, uint32_t hi,
                                        uint64_t f0, uint64_t f1, uint64_t f2, uint32_t* flags) {
     const uint64_t key = ((uint64_t)lo << 32) | hi;

@@ -129,6 +129,38 @@ template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS, int NT = WAVES * 
 __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const int tid, const uint64_t A0,
                                              const uint64_t B0, const uint64_t C0, const uint32_t hot,
                                              const uint32_t wg) {
+    // The pairs first, as far as their first global round trip goes: the home slot of each of this thread's pairs in the
+    // device-global table is READ here and looked at after the labels' (fire-and-forget) atomics have been issued -- a
+    // tile's flush used to wait for a chain of global round trips per pair slot, two slots a thread, one after the other.
+    constexpr int PPT = ADJ ? (PSLOTS + NT - 1) / NT : 1;              // pair slots per thread
+    uint64_t fkey[PPT], fgk[PPT];
+    uint32_t fgh[PPT], ff0[PPT], ff1[PPT], ff2[PPT];
+    if (ADJ) {
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            const int i = tid + j * NT;
+            fkey[j] = i < PSLOTS ? S.pkeys[i] : EMPTY_KEY;
+            fgh[j] = 0u; fgk[j] = EMPTY_KEY; ff0[j] = ff1[j] = ff2[j] = 0u;
+            if (fkey[j] != EMPTY_KEY) {
+                fgh[j] = hash_pair((uint32_t)(fkey[j] >> 32), (uint32_t)fkey[j]) & A.pairs.mask;
+                fgk[j] = __hip_atomic_load(&A.pairs.keys[fgh[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if TA_PCNT64
+                const uint64_t c = S.pcnt[i];
+                ff0[j] = (uint32_t)(c & PCNT_MASK); ff1[j] = (uint32_t)((c >> PCNT_BITS) & PCNT_MASK); ff2[j] = (uint32_t)(c >> (2 * PCNT_BITS));
+#else
+                ff0[j] = S.pcnt[i * 3 + 0]; ff1[j] = S.pcnt[i * 3 + 1]; ff2[j] = S.pcnt[i * 3 + 2];
+#endif
+                if (RESET) {
+                    S.pkeys[i] = EMPTY_KEY;
+#if TA_PCNT64
+                    S.pcnt[i] = 0ull;
+#else
+                    S.pcnt[i * 3 + 0] = 0u; S.pcnt[i * 3 + 1] = 0u; S.pcnt[i * 3 + 2] = 0u;
+#endif
+                }
+            }
+        }
+    }
     uint64_t* const hot_rows = HOT ? hot_rows_of(A) : nullptr;
     for (int i = tid; i < LSLOTS; i += NT) {
         const uint32_t label = S.lkeys[i];
@@ -175,25 +207,10 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
         }
     }
     if (ADJ) {
-        for (int i = tid; i < PSLOTS; i += NT) {
-            const uint64_t key = S.pkeys[i];
-            if (key == EMPTY_KEY) continue;
-#if TA_PCNT64
-            const uint64_t c = S.pcnt[i];
-            pair_add_global(A.pairs, (uint32_t)(key >> 32), (uint32_t)key, c & PCNT_MASK,
-                            (c >> PCNT_BITS) & PCNT_MASK, c >> (2 * PCNT_BITS), A.flags);
-#else
-            pair_add_global(A.pairs, (uint32_t)(key >> 32), (uint32_t)key, S.pcnt[i * 3 + 0],
-                            S.pcnt[i * 3 + 1], S.pcnt[i * 3 + 2], A.flags);
-#endif
-            if (RESET) {
-                S.pkeys[i] = EMPTY_KEY;
-#if TA_PCNT64
-                S.pcnt[i] = 0ull;
-#else
-                S.pcnt[i * 3 + 0] = 0u; S.pcnt[i * 3 + 1] = 0u; S.pcnt[i * 3 + 2] = 0u;
-#endif
-            }
+#pragma unroll
+        for (int j = 0; j < PPT; ++j) {
+            if (fkey[j] != EMPTY_KEY)
+                pair_add_global_from(A.pairs, (uint32_t)(fkey[j] >> 32), (uint32_t)fkey[j], ff0[j], ff1[j], ff2[j], A.flags, fgh[j], fgk[j]);
         }
     }
 }
