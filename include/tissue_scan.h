@@ -131,9 +131,10 @@ TA_API int ta_get_labels(ta_ctx* ctx, uint64_t* count, int32_t* bbox, uint64_t* 
 TA_API int ta_adjacency_size(ta_ctx* ctx, int64_t* npairs);
 TA_API int ta_adjacency_get(ta_ctx* ctx, uint32_t* lo, uint32_t* hi, uint64_t* faces);
 
-/* Timing of the last ta_extract (HIP events on the context stream; zeros when TA_OPT_TIMING is 0): the sweep kernel alone; with TA_OPT_TIMING = 2
+/* Timing of the last ta_extract (HIP events on the context stream): the sweep kernel alone; with TA_OPT_TIMING = 2
  * also what follows it (fold of the per-workgroup hot-label rows + adjacency collection) and the whole call from
- * the accumulator init on (0 otherwise); bytes_read = nvox * itemsize (algorithmic bytes).
+ * the accumulator init on.  A duration that no event recorded (TA_OPT_TIMING 0; the last two under TA_OPT_TIMING 1)
+ * is answered as NaN -- "not measured", never 0; bytes_read = nvox * itemsize (algorithmic bytes).
  * ta_timing_series: the sweep kernel's duration of each of the last extractions (oldest first, at most capacity and
  * at most TA_OPT_TIMING_RING of them) -- drains the stream; how a host times every launch of a pipelined loop. */
 TA_API int ta_timing_series(ta_ctx* ctx, double* ms_sweep, int capacity, int* count);

@@ -18,7 +18,7 @@ def test_series_keeps_the_last_launches_and_modes_switch_events():
         assert ctx.get_option(_capi.OPT_TIMING) == 1 and ctx.get_option(_capi.OPT_TIMING_RING) == 1
         ctx.extract(_capi.F_ALL, L)
         t = ctx.timing()
-        assert t["ms_sweep"] > 0 and t["ms_total"] == 0 and t["ms_adjacency"] == 0      # default: the sweep kernel only
+        assert t["ms_sweep"] > 0 and t["ms_total"] is None and t["ms_adjacency"] is None   # default: the sweep kernel only
         assert t["bytes_read"] == vol.size * 4
         assert len(ctx.timing_series()) == 1
         ctx.set_option(_capi.OPT_TIMING_RING, 5)
@@ -38,8 +38,8 @@ def test_series_keeps_the_last_launches_and_modes_switch_events():
         assert t["ms_total"] >= t["ms_sweep"] > 0 and t["ms_adjacency"] > 0
         ctx.set_option(_capi.OPT_TIMING, 0)
         ctx.extract(_capi.F_ALL, L)
-        t = ctx.timing()                                                                # no events recorded: zeros, not an error
-        assert t["ms_sweep"] == 0 and t["ms_total"] == 0 and t["ms_adjacency"] == 0 and t["bytes_read"] == vol.size * 4
+        t = ctx.timing()                                                                # no events recorded: "not measured", not an error
+        assert t["ms_sweep"] is None and t["ms_total"] is None and t["ms_adjacency"] is None and t["bytes_read"] == vol.size * 4
         assert ctx.timing_series() == []
         counts = ctx.labels()[0]                                                        # results are unaffected
         assert int(counts.sum()) == vol.size

@@ -98,3 +98,20 @@ def test_missing_background_warns_like_the_reference(capsys):
     vol = voronoi((10, 10, 12), 4, 25, np.uint16, ellipsoid=False)
     SpatialImageAnalysis3D(vol, background=60000, extraction=injected(vol))
     assert "has not been detected" in capsys.readouterr().out
+
+
+def test_neighbors_number_under_nplist_answers_for_the_labels_as_asked():
+    """One degree per label of the request, in the caller's order; an id the image does not hold has no neighbour; with
+    labels=None the k-th value belongs to the k-th key of boundingbox() (labels, then the background)."""
+    vol = voronoi((16, 18, 20), 9, 24, np.uint16)
+    x = injected(vol)
+    arr = SpatialImageAnalysis3D(vol, return_type=NPLIST, background=1, extraction=x)
+    dct = SpatialImageAnalysis3D(vol, return_type=DICT, background=1, extraction=x)
+    labs = dct.labels()
+    ask = [labs[3], labs[1], 10 ** 6, labs[2]]
+    want = dct.neighbors_number([labs[3], labs[1], labs[2]])
+    got = arr.neighbors_number(ask)
+    assert got.tolist() == [want[labs[3]], want[labs[1]], 0, want[labs[2]]]
+    everything = dct.neighbors_number()
+    keys = labs + [1] if 1 not in labs else labs
+    assert arr.neighbors_number().tolist() == [everything[k] for k in keys]

@@ -7,7 +7,7 @@ import pytest
 
 from oracle import onepass, sia_oracle
 from oracle.sia_oracle import OracleSIA
-from tissue_analysis_amd import DICT, Extraction, SpatialImage, SpatialImageAnalysis3D
+from tissue_analysis_amd import DICT, LIST, NPLIST, Extraction, SpatialImage, SpatialImageAnalysis3D
 
 from helpers import WALL_OFFSETS, random_blocks, voronoi
 
@@ -64,6 +64,22 @@ def test_cells_voxel_layer_against_the_erosions(make):
     cut = (slice(2, 8), slice(1, 9), slice(3, 10))                                                      # a crop that cuts cells
     same(sia.cells_voxel_layer(list(labels), region_boundingbox=cut), ref.cells_voxel_layer(list(labels), region_boundingbox=cut))
     assert sia.cells_voxel_layer(list(labels), region_boundingbox=(1, 2, 3)) is None
+
+
+def test_cells_voxel_layer_and_region_boundingbox_do_not_depend_on_the_return_type():
+    """Under NPLIST `boundingbox(list)` answers with an [n, 6] array; the methods that CROP the image with bounding boxes must
+    still get slices (an [n, 6] row used as an index fancy-indexes axis 0: wrong masks, no error)."""
+    vol = voronoi((18, 16, 22), 14, 81, np.uint16)
+    want_sia, _ = both(vol, ignoredlabels=0, background=1)
+    labels = want_sia.labels()[:5]
+    for rt in (NPLIST, LIST):
+        x = Extraction.from_arrays(vol.shape, onepass.extract(vol))
+        sia = SpatialImageAnalysis3D(SpatialImage(vol, voxelsize=(1., 1., 1.)), return_type=rt, extraction=x, ignoredlabels=0, background=1)
+        sia._voxel_layer18 = brute_layer18(vol)
+        assert sia.region_boundingbox(list(labels)) == want_sia.region_boundingbox(list(labels))
+        same(sia.cells_voxel_layer(list(labels)), want_sia.cells_voxel_layer(list(labels)))
+        same(sia.cells_voxel_layer(list(labels), region_boundingbox=True), want_sia.cells_voxel_layer(list(labels), region_boundingbox=True))
+        same(sia.cells_voxel_layer(list(labels), single_frame=True), want_sia.cells_voxel_layer(list(labels), single_frame=True))
 
 
 def test_the_oracle_hollow_is_the_modular_laplacian():

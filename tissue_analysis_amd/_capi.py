@@ -366,7 +366,10 @@ class Context(object):
         nbytes = ctypes.c_uint64(0)
         _check(self._lib.ta_timing(self._h, ctypes.byref(a), ctypes.byref(b), ctypes.byref(t),
                                    ctypes.byref(nbytes)))
-        return dict(ms_sweep=a.value, ms_adjacency=b.value, ms_total=t.value, bytes_read=nbytes.value)
+        # (a duration no event recorded comes back as NaN -- TA_OPT_TIMING 0, or 1 for what only mode 2 brackets -- and is
+        #  handed on as None: "not measured" must never read as "took no time" in a bandwidth figure)
+        some = lambda v: None if v != v else v
+        return dict(ms_sweep=some(a.value), ms_adjacency=some(b.value), ms_total=some(t.value), bytes_read=nbytes.value)
 
     def timing_series(self, capacity=4096):
         """Sweep-kernel milliseconds of the last extractions (oldest first; OPT_TIMING_RING of them at most)."""

@@ -629,7 +629,9 @@ WallPlan wall_plan(int64_t n0, int64_t n1, int64_t n2) {
     return p;
 }
 
-uint64_t wall_stage_bytes(uint64_t records_per_region) { return (uint64_t)WALL_CURSORS * records_per_region * sizeof(WallStaged); }
+uint64_t wall_stage_bytes(uint64_t records_per_region, int itemsize) {
+    return (uint64_t)WALL_CURSORS * records_per_region * (itemsize == 2 ? sizeof(WallStagedNarrow) : sizeof(WallStaged));
+}
 uint64_t wall_cursor_bytes() { return (uint64_t)WALL_CURSORS * 128; }
 uint32_t wall_stage_regions() { return WALL_CURSORS; }
 

@@ -3,6 +3,7 @@
 #include "ta_kernels.h"
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -539,6 +540,8 @@ TA_API int ta_volume_relabel(ta_ctx* c, const uint32_t* lut, uint32_t lut_len) {
     d.release();
     if (e != hipSuccess) return fail(TA_EHIP, "relabel: %s", hipGetErrorString(e));
     c->extracted = c->checked = false;
+    c->wall_records = -1;           // the staged wall records carry the OLD labels: a fetch must ask for a fresh count
+    c->wall_region = 0; c->wall_not_staged = 0;
     return TA_OK;
 }
 
@@ -660,21 +663,23 @@ uint64_t wall_bufs(void* base, const ta::WallPlan& p, ta::WallBuffers& b) {
 void wall_stage(ta_ctx* c, const ta::WallPlan& p, ta::WallBuffers& b) {
     const uint64_t nvox = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2];
     uint64_t records = std::min<uint64_t>(std::max<uint64_t>(nvox / 2, 1u << 16), 1ull << 31);
-    if (const char* env = getenv("TA_WALL_STAGE_RECORDS")) records = std::strtoull(env, nullptr, 10);      // tests: force the second walk
+    // (tests: force the second walk / small regions.  Clamped: region_of_wave * region + got must stay below 2^32 in the kernel)
+    if (const char* env = getenv("TA_WALL_STAGE_RECORDS")) records = std::min<uint64_t>(std::strtoull(env, nullptr, 10), 1ull << 31);
     const uint32_t regions = ta::wall_stage_regions();
     b.region = (uint32_t)(records / regions);
     b.stage = nullptr;
     (void)p;
     if (b.region == 0) return;
-    if (c->wall_stage.bytes < ta::wall_stage_bytes(b.region)) {
+    const uint64_t need = ta::wall_stage_bytes(b.region, c->itemsize);
+    if (c->wall_stage.bytes < need) {
         c->wall_stage.release();
-        if (hipMalloc(&c->wall_stage.p, ta::wall_stage_bytes(b.region)) != hipSuccess) {
+        if (hipMalloc(&c->wall_stage.p, need) != hipSuccess) {
             (void)hipGetLastError();
             c->wall_stage.p = nullptr;
             b.region = 0;
             return;
         }
-        c->wall_stage.bytes = ta::wall_stage_bytes(b.region);
+        c->wall_stage.bytes = need;
     }
     b.stage = c->wall_stage.p;
 }
@@ -980,7 +985,8 @@ TA_API int ta_timing(ta_ctx* c, double* ms_sweep, double* ms_adjacency, double* 
     int rc = use_device(c);
     if (rc != TA_OK) return rc;
     const size_t nslots = c->ring.size() / 2;
-    float a = 0, b = 0, t = 0;
+    // (durations no event recorded are NaN, not 0: "not measured" must not read as "took no time" in a bandwidth figure)
+    float a = NAN, b = NAN, t = NAN;
     if (c->extract_seq > c->ring_since && nslots) {          // the last extraction recorded its sweep events
         hipEvent_t ev_a = c->ring[2 * ((c->extract_seq - 1) % nslots)], ev_b = c->ring[2 * ((c->extract_seq - 1) % nslots) + 1];
         TA_HIP(hipEventSynchronize(ev_b));
@@ -990,7 +996,7 @@ TA_API int ta_timing(ta_ctx* c, double* ms_sweep, double* ms_adjacency, double* 
             TA_HIP(hipEventElapsedTime(&b, ev_b, c->ev[3]));
             TA_HIP(hipEventElapsedTime(&t, c->ev[0], c->ev[3]));
         }
-    }      // (else: the last extraction recorded no events -- TA_OPT_TIMING is 0 -- and the durations are answered as zero)
+    }      // (else: the last extraction recorded no events -- TA_OPT_TIMING is 0)
     if (ms_sweep) *ms_sweep = a;
     if (ms_adjacency) *ms_adjacency = b;
     if (ms_total) *ms_total = t;

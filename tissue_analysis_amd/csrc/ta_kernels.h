@@ -53,7 +53,7 @@ struct WallBuffers {
     uint32_t* todo;          // [cells] the cells left to the second walk
     uint32_t region;         // records per staging region
 };
-uint64_t wall_stage_bytes(uint64_t records_per_region);
+uint64_t wall_stage_bytes(uint64_t records_per_region, int itemsize);      // 8-byte records for uint16 volumes, 12-byte ones for uint32
 uint64_t wall_cursor_bytes();
 uint32_t wall_stage_regions();
 void launch_wall_count(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2, const WallBuffers& b,

@@ -292,6 +292,12 @@ class AbstractSpatialImageAnalysis(object):
             self._bbox = self._x.bbox_slices_upto(top)
         return self._bbox
 
+    def _bbox_slices(self, labels):
+        """label -> (slice, slice, slice) or None, whatever `return_type` is: what the methods that crop the image need
+        (under NPLIST `boundingbox(list)` answers with an [n, 6] array, which indexes nothing)."""
+        boxes = self._bbox_list()
+        return dict((c, boxes[c - 1] if 1 <= c <= len(boxes) else None) for c in labels)
+
     def boundingbox(self, labels=None, real=False):
         if labels is not None and not isinstance(labels, list) and labels == 0:
             zero = self._x.bbox_slices(0)
@@ -387,9 +393,18 @@ class AbstractSpatialImageAnalysis(object):
 
     def neighbors_number(self, labels=None, min_contact_area=None, real_area=True, verbose=True):
         if self.return_type == NPLIST and min_contact_area is None and (labels is None or isinstance(labels, list)):
-            idx = self._request_array(labels) if labels is not None else np.asarray(list(self._all_neighbors()), dtype=np.int64)
+            # one degree per label AS ASKED FOR, in the caller's order (an id the image does not hold has no neighbour);
+            # labels=None: the keys of _all_neighbors are positions 1..n (SIA:642-645), the k-th value belongs to the k-th label
+            if labels is None:
+                keys = copy.copy(self.labels())
+                if self.background() is not None:
+                    keys.append(self.background())
+                idx = np.asarray(keys, dtype=np.int64)
+            else:
+                idx = np.asarray(labels, dtype=np.int64)
             degree = self._x.degrees()
-            return degree[np.where((idx >= 0) & (idx < degree.size), idx, degree.size - 1)]
+            known = (idx >= 0) & (idx < degree.size)
+            return np.where(known, degree[np.where(known, idx, 0)], 0)
         nei = self.neighbors(labels, min_contact_area, real_area, verbose)
         if isinstance(nei, dict):
             return dict((k, len(v)) for k, v in nei.items())
@@ -528,9 +543,7 @@ class AbstractSpatialImageAnalysis(object):
         elif region_boundingbox:
             bbox = self.region_boundingbox(labels)
         else:
-            bboxes = self.boundingbox(labels, real=False)
-            if not isinstance(bboxes, dict):
-                bboxes = dict(zip(labels, bboxes))
+            bboxes = self._bbox_slices(labels)
         image, differs = np.asarray(self.image), self._layer18()
         vox_layer = np.zeros_like(image[bbox], dtype=int) if single_frame else {}
         clabel = None
@@ -762,9 +775,7 @@ class SpatialImageAnalysis3D(AbstractSpatialImageAnalysis):
             return self.boundingbox(labels[0])
         if isinstance(labels, _INT):
             return self.boundingbox(labels)
-        boxes = self.boundingbox(labels)
-        if not isinstance(boxes, dict):
-            boxes = dict(zip(labels, boxes))
+        boxes = self._bbox_slices(labels)
         missing = [c for c in labels if c not in boxes or boxes[c] is None]
         if missing:
             warnings.warn("You have asked for unknown cells labels: " + " ".join(str(k) for k in missing))
