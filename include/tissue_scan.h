@@ -34,7 +34,7 @@ extern "C" {
 /* 2: ta_wall_voxels_get takes (pairs, coords, ms); ta_ctx_set_stream(NULL) = the device's legacy default stream;
  *    TA_OPT_IMPL is 0 or 1; ta_adjacency_scope added; ta_timing answers zeros when no events were recorded.
  * A caller checks ta_version() == TA_ABI_VERSION of the header it was built against (the ctypes binding does). */
-#define TA_ABI_VERSION 2
+#define TA_ABI_VERSION 3
 
 #if defined(TA_BUILD)
 #define TA_API __attribute__((visibility("default")))
@@ -111,6 +111,12 @@ TA_API int ta_volume_set_device(ta_ctx* ctx, const void* dev_ptr, int itemsize,
 
 /* Largest label in the resident volume (device max-reduction; ~ np.unique(image) SIA:363). */
 TA_API int ta_volume_max_label(ta_ctx* ctx, uint32_t* max_label);
+
+/* events[p] = label changes along memory axis 2 in OWNED plane p of the resident volume (one streaming pass; the halo
+ * plane of a slab is not counted): what a record-producing plane costs the sweep on top of its voxels -- the weight a
+ * Z-slab partition balances (tissue_analysis_amd/distributed.py: plane_costs, balanced_cuts).  New in
+ * TA_ABI_VERSION 3; nothing in the reference to mirror. */
+TA_API int ta_volume_plane_events(ta_ctx* ctx, uint64_t* events /* [owned planes] */);
 
 /* The hot path: one fused sweep of the resident volume + adjacency compaction.
  * Replaces the four per-label Python loops of the reference (SIA:417-480, 632-660, 908-993,

@@ -56,3 +56,33 @@ def brute_wall_records(vol):
     r = np.unique(np.concatenate(recs), axis=0)
     coords = np.stack(np.unravel_index(r[:, 2], vol.shape), axis=1).astype(np.int32)
     return r[:, 0].astype(np.uint32), r[:, 1].astype(np.uint32), coords
+
+
+# ---- the C one-pass oracle on a volume too big for one process to finish in seconds: Z-slabs on forked workers + merge
+_PAR_VOLUME = None
+
+
+def _par_slab(args):
+    from oracle import onepass_c
+    lo, hi, max_label = args
+    halo = 1 if lo > 0 else 0                 # (a face belongs to the slab that owns its higher voxel along axis 0)
+    return onepass_c.extract(_PAR_VOLUME[lo - halo:hi], max_label=max_label, origin=(lo - halo, 0, 0), own_first_plane=not halo)
+
+
+def onepass_c_parallel(vol, max_label, workers=16):
+    """oracle/onepass_c over `workers` Z-slabs (one low halo plane each) in forked processes -- the voxels are inherited, not
+    pickled -- merged with oracle/onepass.merge: the whole-volume result (tests prove slab + merge == unsharded at small sizes)."""
+    import multiprocessing as mp
+    from oracle import onepass, onepass_c
+    global _PAR_VOLUME
+    onepass_c.build()
+    n0 = vol.shape[0]
+    cuts = [n0 * i // workers for i in range(workers + 1)]
+    jobs = [(a, b, max_label) for a, b in zip(cuts[:-1], cuts[1:]) if b > a]
+    _PAR_VOLUME = vol
+    try:
+        with mp.get_context("fork").Pool(len(jobs)) as pool:
+            parts = pool.map(_par_slab, jobs)
+    finally:
+        _PAR_VOLUME = None
+    return onepass.merge(parts)

@@ -62,6 +62,81 @@ def test_two_rank_reduce_equals_unsharded(dims, n_cells):
     assert all(r[1] for r in results), results
 
 
+def _balanced_worker(rank, world, port, dims, n_cells, seed, out_q):
+    """Cost-balanced cuts + the reduce-scatter of the sums (gloo: an all-reduce of a copy, then the rank's rows): every rank
+    ends with the GLOBAL rows of its share of the labels, the gathered table equals the unsharded one, the boxes are global."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import onepass
+        from tissue_analysis_amd import distributed as tad, synth
+        vol = synth.voronoi_labels(dims, n_cells, seed, np.uint16)
+        whole = onepass.extract(vol)
+        L = whole["max_label"]
+        # the plane weights: label changes along the fast axis, counted by every rank on an equal first split and summed
+        lo0, hi0 = tad.slab_range(dims[0], world, rank)
+        ev = torch.zeros(dims[0], dtype=torch.int64)
+        ev[lo0:hi0] = torch.from_numpy((vol[lo0:hi0, :, 1:] != vol[lo0:hi0, :, :-1]).sum(axis=(1, 2)).astype(np.int64))
+        dist.all_reduce(ev)
+        cuts = tad.balanced_cuts(tad.plane_costs(ev.numpy(), dims[1] * dims[2]), world)
+        lo, hi = tad.slab_range(dims[0], world, rank, cuts)
+        halo = 1 if lo > 0 else 0
+        part = onepass.extract(vol[lo - halo:hi], max_label=L, origin=(lo - halo, 0, 0), own_first_plane=not halo)
+        sums, boxes = tad.to_device_layout(part)
+        S = tad.sums_shard_rows(L + 1, world)
+        padded = np.zeros((world * S, 10), dtype=np.int64)
+        padded[:L + 1] = sums
+        sums_t, boxes_t, shard = torch.from_numpy(padded), torch.from_numpy(boxes), torch.zeros((S, 10), dtype=torch.int64)
+        tad.reduce_scatter_sums(sums_t, shard)
+        dist.all_reduce(boxes_t, op=dist.ReduceOp.MIN)
+        gsums, _ = tad.to_device_layout(whole)
+        want = np.zeros((world * S, 10), dtype=np.int64)
+        want[:L + 1] = gsums
+        ok = np.array_equal(shard.numpy(), want[rank * S:(rank + 1) * S])              # this rank's labels: global rows
+        ok = ok and np.array_equal(sums_t.numpy()[:L + 1], sums)                          # the slab's own rows are untouched
+        merged = tad.from_device_layout(tad.allgather_sums(shard, L + 1).numpy(), boxes_t.numpy())
+        ok = ok and all(np.array_equal(merged[k], whole[k]) for k in ("count", "bbox", "sum1", "sum2"))
+        out_q.put((rank, bool(ok), [int(c) for c in cuts]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,dims,n_cells", [(2, (30, 16, 24), 20), (3, (41, 12, 20), 16)])
+def test_balanced_cuts_and_reduce_scatter_give_the_unsharded_rows(world, dims, n_cells):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_balanced_worker, args=(r, world, port, dims, n_cells, 33, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in results), results
+    cuts = results[0][2]
+    assert all(r[2] == cuts for r in results) and cuts[0] == 0 and cuts[-1] == dims[0] and all(b > a for a, b in zip(cuts, cuts[1:]))
+
+
+def test_balanced_cuts_equalise_the_cost():
+    from tissue_analysis_amd import distributed as tad
+    n0 = 2048
+    a = np.arange(n0)
+    events = np.clip(1.0 - ((a - (n0 - 1) / 2.0) / (0.45 * n0)) ** 2, 0.0, None) * 1.2e5      # a tissue inside an ellipsoid
+    costs = tad.plane_costs(events, 2048 * 2048)
+    for world in (2, 4, 8):
+        cuts = tad.balanced_cuts(costs, world)
+        slabs = np.array([costs[cuts[r]:cuts[r + 1]].sum() for r in range(world)])
+        assert slabs.max() / slabs.mean() < 1.01, (world, cuts)
+        equal = np.array([costs[slice(*tad.slab_range(n0, world, r))].sum() for r in range(world)])
+        assert world == 2 or equal.max() / equal.mean() > 1.05                                # what equal plane counts leave
+    assert tad.balanced_cuts(np.ones(5), 5) == [0, 1, 2, 3, 4, 5]
+    assert tad.balanced_cuts(np.array([100.0, 1, 1, 1, 1, 1]), 3) == [0, 1, 2, 6] or tad.balanced_cuts(np.array([100.0, 1, 1, 1, 1, 1]), 3)[1] == 1
+    with pytest.raises(ValueError):
+        tad.balanced_cuts(np.ones(3), 4)
+
+
 def test_slab_ranges_partition_the_axis():
     from tissue_analysis_amd import distributed as tad
     for n0 in (1, 7, 64, 1000):

@@ -21,7 +21,7 @@ def test_bench_line_has_the_contract_fields():
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["warmup"] == 1 and d["vs_baseline"] is None and d["higher_is_better"] is True
-    assert d["scaling"] == "weak" and "workload" in d["config"] and "model" not in d["config"]
+    assert d["scaling"] == "strong" and "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k

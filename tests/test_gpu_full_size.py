@@ -6,7 +6,9 @@ C2: 512^3 uint16, 5 000 seeds at its stated size: its own feature subset (volume
 full feature set.  The tissue-filled C4 (the same generator WITHOUT the ellipsoid mask: 50 653 labels present, the
 densest workload bench.py quotes): full feature set.
 C5: 2048^3 uint32, 100k seeds (34 GB) on one GPU: size-independent identities at full scale, three 32-plane windows
-(first / middle / last) bit-exact against the C oracle, and eight virtual Z-slabs with halo planes merged == unsharded.
+(first / middle / last) bit-exact against the C oracle, eight virtual Z-slabs with halo planes merged == unsharded, and
+the WHOLE volume against the C oracle run on 16 forked host processes over Z-slabs (skipped, with a printed reason, on a
+host without ~46 GB of free memory).
 """
 import numpy as np
 import pytest
@@ -14,7 +16,7 @@ import pytest
 from oracle import onepass, onepass_c
 from tissue_analysis_amd import _capi, device as dev, synth
 
-from helpers import assert_same_accumulators
+from helpers import assert_same_accumulators, onepass_c_parallel
 
 pytestmark = pytest.mark.gpu
 KEYS = ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces")
@@ -176,10 +178,31 @@ def test_c5_on_one_gpu_identities_windows_and_virtual_slabs():
         ctx.extract(_capi.F_ALL, L)
         parts.append(fetch(ctx, L))
     ctx.close()
-    del vol
     merged = onepass.merge(parts)
     for k in KEYS:
         assert np.array_equal(merged[k], whole[k]), "8 slabs vs unsharded: " + k
+    del merged, parts
+
+    # -- the WHOLE 2048^3 volume against the C oracle: 34 GB to the host, 16 forked workers over Z-slabs
+    #    (~0.5 Gvoxel/s) + merge; every integer array bit-exact.  Needs the volume in host memory next to the workers' results.
+    import os
+    import time
+    import psutil
+    need = vol.numel() * vol.element_size() + (12 << 30)
+    if psutil.virtual_memory().available < need:
+        print("C5 in full against the oracle: SKIPPED, %.0f GB of host memory available, %.0f needed"
+              % (psutil.virtual_memory().available / 2 ** 30, need / 2 ** 30))
+        return
+    t0 = time.perf_counter()
+    host = vol.cpu().numpy().view(dtype)
+    del vol
+    torch.cuda.empty_cache()
+    t1 = time.perf_counter()
+    want = onepass_c_parallel(host, L, workers=min(16, os.cpu_count() or 1))
+    t2 = time.perf_counter()
+    print("C5 in full against the oracle: %.1f s to the host, %.1f s oracle (%d labels, %d pairs)"
+          % (t1 - t0, t2 - t1, int((want["count"] > 0).sum()), want["pair_lo"].size))
+    assert_same_accumulators(whole, want, "C5 2048^3 full feature set, whole volume")
 
 
 def test_c5_exchange_budget_eight_contexts_on_one_gpu(capsys):

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None, pair_slots=0, depth=1, features=31):
+def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None, pair_slots=0, depth=1, features=31, balanced=False):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -29,16 +29,34 @@ def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None
         lo, hi = tad.slab_range(dims[0], world, rank)
         halo = 1 if lo > 0 else 0
         vol, max_label = dev.synth_slab(ctx, dims, dtype, n_cells, seed, lo - halo, hi, device=0)
+        reduce = "all"
+        events_ok = True
+        if balanced:
+            # cost-balanced slabs + reduce-scattered sums (what bench.py --gpus N runs): the ranks count the label changes
+            # of their planes on the device, agree on the cuts and generate their slabs again
+            torch.cuda.synchronize()
+            ctx.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, a0_origin=lo, has_low_halo=bool(halo), keep=vol)
+            mine = torch.zeros(dims[0], dtype=torch.int64)
+            ev = ctx.plane_events()
+            host = vol.cpu().numpy().view(dtype)[halo:]
+            events_ok = np.array_equal(ev, (host[:, :, 1:] != host[:, :, :-1]).sum(axis=(1, 2)).astype(np.uint64))
+            mine[lo:hi] = torch.from_numpy(ev.astype(np.int64))
+            dist.all_reduce(mine)
+            cuts = tad.balanced_cuts(tad.plane_costs(mine.numpy(), dims[1] * dims[2]), world)
+            lo, hi = tad.slab_range(dims[0], world, rank, cuts)
+            halo = 1 if lo > 0 else 0
+            vol, max_label = dev.synth_slab(ctx, dims, dtype, n_cells, seed, lo - halo, hi, device=0)
+            reduce = "scatter"
         if pair_slots and rank == 1:    # one rank starts with a table far too small: sizes must be agreed on
             ctx.set_option(_capi.OPT_PAIR_SLOTS, pair_slots)
         if depth > 1:                   # two steps in flight on two streams / contexts
             job = tad.PipelinedSlabJob(vol, dtype.itemsize, a_origin=lo, has_low_halo=bool(halo), max_label=max_label,
-                                       features=features, group=dist.group.WORLD, device=0, depth=depth)
+                                       features=features, group=dist.group.WORLD, device=0, depth=depth, reduce=reduce)
             for _ in range(3):
                 job.step()
         else:
             job = tad.SlabJob(ctx, vol, dtype.itemsize, a_origin=lo, has_low_halo=bool(halo), max_label=max_label,
-                              features=features, group=dist.group.WORLD, device=0, exchange_capacity=capacity)
+                              features=features, group=dist.group.WORLD, device=0, exchange_capacity=capacity, reduce=reduce)
             ctx.extract(features, max_label)          # (a plain sweep first: the exchange resets the diagnostic counters)
             spills = ctx.debug_counters()["label_spills"]
             job.step()
@@ -54,6 +72,9 @@ def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None
                  ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces"))
         bad = [k for k in ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces")
                if not (got[k].shape == want[k].shape and np.array_equal(got[k], want[k]))]
+        if balanced:
+            ok = ok and events_ok and job.result_counts().shape[0] == max_label + 1
+            bad.append("plane_events=%s" % events_ok)
         if capacity:                    # a block that small must have forced exactly one collective redo
             ok = ok and job.redo_count == 1
             bad.append("redo_count=%d" % job.redo_count)
@@ -66,20 +87,22 @@ def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("dims,n_cells,dtype_name,capacity,pair_slots,depth,features", [
-    ((37, 40, 264), 50, "uint32", None, 0, 1, 31),
-    ((20, 24, 520), 30, "uint16", None, 0, 1, 31),
-    ((37, 40, 264), 50, "uint32", 8, 0, 1, 31),        # exchange blocks too small: verdict -> re-size -> redo
-    ((37, 40, 264), 50, "uint32", None, 6, 1, 31),     # rank 1 starts with a 64-slot table: grown and agreed on
-    ((37, 40, 264), 50, "uint32", None, 0, 2, 31),     # PipelinedSlabJob: steps alternate between two streams
-    ((37, 40, 264), 20000, "uint32", None, 0, 1, 0x17),   # tiny cells (table spills) WITHOUT second moments: sum2 must read as zero
+@pytest.mark.parametrize("dims,n_cells,dtype_name,capacity,pair_slots,depth,features,balanced", [
+    ((37, 40, 264), 50, "uint32", None, 0, 1, 31, False),
+    ((20, 24, 520), 30, "uint16", None, 0, 1, 31, False),
+    ((37, 40, 264), 50, "uint32", 8, 0, 1, 31, False),        # exchange blocks too small: verdict -> re-size -> redo
+    ((37, 40, 264), 50, "uint32", None, 6, 1, 31, False),     # rank 1 starts with a 64-slot table: grown and agreed on
+    ((37, 40, 264), 50, "uint32", None, 0, 2, 31, False),     # PipelinedSlabJob: steps alternate between two streams
+    ((37, 40, 264), 20000, "uint32", None, 0, 1, 0x17, False),   # tiny cells (table spills) WITHOUT second moments: sum2 must read as zero
+    ((37, 40, 264), 50, "uint32", None, 0, 1, 31, True),      # slabs cut by cost (ta_volume_plane_events), sums reduce-scattered
+    ((21, 24, 520), 30, "uint16", None, 0, 2, 31, True),      # ... two steps in flight
 ])
-def test_two_ranks_on_one_gpu_match_unsharded(dims, n_cells, dtype_name, capacity, pair_slots, depth, features):
+def test_two_ranks_on_one_gpu_match_unsharded(dims, n_cells, dtype_name, capacity, pair_slots, depth, features, balanced):
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29800 + (os.getpid() % 1000)
-    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, n_cells, 61, dtype_name, q, capacity, pair_slots, depth, features))
+    procs = [ctx.Process(target=_worker, args=(r, world, port, dims, n_cells, 61, dtype_name, q, capacity, pair_slots, depth, features, balanced))
              for r in range(world)]
     for p in procs:
         p.start()

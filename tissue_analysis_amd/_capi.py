@@ -17,7 +17,7 @@ TA_OK, TA_EINVAL, TA_EHIP, TA_ENOMEM, TA_ERANGE, TA_ECAPACITY, TA_ENODEVICE = 0,
 F_VOLUME, F_BBOX, F_MOMENT1, F_MOMENT2, F_ADJACENCY = 1, 2, 4, 8, 16
 F_ALL = 31
 ADJ_LOCAL, ADJ_MERGED, ADJ_PARTIAL = 0, 1, 2
-ABI_VERSION = 2          # TA_ABI_VERSION of include/tissue_scan.h this binding was written against
+ABI_VERSION = 3          # TA_ABI_VERSION of include/tissue_scan.h this binding was written against
 FEATURES = dict(VOLUME=F_VOLUME, BBOX=F_BBOX, MOMENT1=F_MOMENT1, MOMENT2=F_MOMENT2,
                 ADJACENCY=F_ADJACENCY)
 OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS, OPT_TIMING, OPT_TIMING_RING, OPT_VOLUME_SLACK = 1, 2, 3, 4, 5, 6
@@ -27,7 +27,7 @@ STREAM_LEGACY_DEFAULT = 1          # TA_STREAM_LEGACY_DEFAULT of include/tissue_
 SYMBOLS = (
     "ta_version", "ta_adjacency_scope", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_get_option", "ta_ctx_synchronize", "ta_volume_set",
-    "ta_volume_set_device", "ta_volume_max_label", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
+    "ta_volume_set_device", "ta_volume_max_label", "ta_volume_plane_events", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
     "ta_volume_first_layer", "ta_volume_hollow", "ta_volume_layer18", "ta_wall_voxels_count", "ta_wall_voxels_get", "ta_wall_voxels_get_by_pair",
     "ta_extract", "ta_get_labels",
     "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_timing_series", "ta_read_probe", "ta_debug_counters", "ta_bind_accumulators",
@@ -86,6 +86,7 @@ def load():
         "ta_volume_set": (ci, [vp, vp, ci, P(i64), P(i64)]),
         "ta_volume_set_device": (ci, [vp, vp, ci, P(i64), i64, ci]),
         "ta_volume_max_label": (ci, [vp, P(u32)]),
+        "ta_volume_plane_events": (ci, [vp, vp]),
         "ta_volume_relabel": (ci, [vp, vp, u32]),
         "ta_volume_get": (ci, [vp, vp]),
         "ta_volume_map": (ci, [vp, vp, u32, vp, ci, vp]),
@@ -228,6 +229,7 @@ class Context(object):
             a = np.ascontiguousarray(a)
         _check(self._lib.ta_volume_set(self._h, ctypes.c_void_p(a.ctypes.data), a.dtype.itemsize,
                                        _i64x3(a.shape), _i64x3(a.strides)))
+        self._owned_planes = int(a.shape[int(np.argmax(a.strides))])         # planes of the slowest MEMORY axis
 
     def relabel(self, lut):
         """In place on the resident volume: v -> lut[v] for v < len(lut) (host uint32 table)."""
@@ -304,6 +306,7 @@ class Context(object):
         _check(self._lib.ta_volume_set_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(itemsize),
                                               _i64x3(buf_dims), int(a0_origin), int(bool(has_low_halo))))
         self._keep = [keep]
+        self._owned_planes = int(buf_dims[0]) - (1 if has_low_halo else 0)
         # a torch tensor that is a view of a larger storage: tell the library how many bytes are readable behind it
         try:
             st = keep.untyped_storage()
@@ -319,6 +322,13 @@ class Context(object):
         return v.value
 
     # -- hot path
+    def plane_events(self):
+        """uint64[owned planes]: label changes along the fast axis in every owned plane of the resident volume (the weight
+        distributed.balanced_cuts balances)."""
+        out = np.zeros(self._owned_planes, dtype=np.uint64)
+        _check(self._lib.ta_volume_plane_events(self._h, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
     def extract(self, features, max_label):
         _check(self._lib.ta_extract(self._h, feature_mask(features), int(max_label)))
         self._max_label = int(max_label)

@@ -36,6 +36,45 @@ void launch_init_accumulators(hipStream_t s, uint64_t* sums, int32_t* boxes, uin
 }
 
 // ------------------------------------------------------------------------------------------
+// Label changes along the fast axis, per plane of axis 0: the weight a Z-slab partition balances (a record of the sweep per
+// change; distributed.balanced_cuts).  One pass at streaming speed, run once per resident volume -- not part of a step.
+template <typename T>
+__global__ void __launch_bounds__(256) plane_events_kernel(const T* vol, int64_t n1, int64_t n2, unsigned long long* out) {
+    const int64_t plane = blockIdx.y, rows_per_block = (n1 + gridDim.x - 1) / gridDim.x;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < n1 ? r0 + rows_per_block : n1;
+    const T* p = vol + plane * n1 * n2;
+    uint32_t mine = 0;
+    for (int64_t i = r0 * n2 + threadIdx.x; i < r1 * n2; i += 256) {
+        const int64_t c = i % n2;
+        mine += (c > 0 && p[i] != p[i - 1]) ? 1u : 0u;
+    }
+    __shared__ uint32_t part[256];
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && part[0]) atomicAdd(out + plane, (unsigned long long)part[0]);
+}
+
+void launch_plane_events(hipStream_t s, const void* vol, int itemsize, int64_t planes, int64_t n1, int64_t n2, uint64_t* out_dev) {
+    (void)hipMemsetAsync(out_dev, 0, (size_t)planes * sizeof(uint64_t), s);
+    if (planes <= 0 || n1 <= 0 || n2 <= 0) return;
+    const unsigned bx = (unsigned)(n1 < 16 ? n1 : 16);
+    for (int64_t done = 0; done < planes; done += 32768) {          // (gridDim.y <= 65535)
+        const unsigned by = (unsigned)(planes - done < 32768 ? planes - done : 32768);
+        const char* base = (const char*)vol + (size_t)done * n1 * n2 * itemsize;
+        if (itemsize == 2)
+            hipLaunchKernelGGL(plane_events_kernel<uint16_t>, dim3(bx, by), dim3(256), 0, s, (const uint16_t*)base, n1, n2,
+                               (unsigned long long*)(out_dev + done));
+        else
+            hipLaunchKernelGGL(plane_events_kernel<uint32_t>, dim3(bx, by), dim3(256), 0, s, (const uint32_t*)base, n1, n2,
+                               (unsigned long long*)(out_dev + done));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // Cross-check kernel: one thread per voxel, every contribution a global atomic.  Slow by design;
 // it shares no logic with the fused sweep beyond the accumulator layout, so the two check each
 // other on the GPU (and both are checked against the CPU oracle by the tests).

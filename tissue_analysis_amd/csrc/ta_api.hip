@@ -819,6 +819,25 @@ TA_API int ta_volume_max_label(ta_ctx* c, uint32_t* max_label) {
     return TA_OK;
 }
 
+TA_API int ta_volume_plane_events(ta_ctx* c, uint64_t* events) {
+    if (!c || !events) return fail(TA_EINVAL, "NULL argument");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const int64_t owned = c->mdims[0] - c->first_owned;
+    if (owned <= 0) return TA_OK;
+    DevBuf d;
+    if ((rc = d.reserve((uint64_t)owned * sizeof(uint64_t))) != TA_OK) return rc;
+    const char* first = (const char*)c->vol + (size_t)c->first_owned * c->mdims[1] * c->mdims[2] * c->itemsize;
+    ta::launch_plane_events(c->stream, first, c->itemsize, owned, c->mdims[1], c->mdims[2], (uint64_t*)d.p);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(events, d.p, (size_t)owned * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    d.release();
+    if (e != hipSuccess) return fail(TA_EHIP, "plane events: %s", hipGetErrorString(e));
+    return TA_OK;
+}
+
 TA_API int ta_bind_accumulators(ta_ctx* c, void* sums_dev, void* boxes_dev, uint32_t max_label) {
     if (!c) return fail(TA_EINVAL, "ctx is NULL");
     if ((sums_dev == nullptr) != (boxes_dev == nullptr)) return fail(TA_EINVAL, "bind both buffers or neither");

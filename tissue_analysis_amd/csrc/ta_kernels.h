@@ -9,6 +9,7 @@ void launch_init_accumulators(hipStream_t s, uint64_t* sums, int32_t* boxes, uin
                               uint32_t* flags, uint32_t* pair_cursor, uint64_t* hot_rows);
 void launch_naive(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask);
 void launch_max_label(hipStream_t s, const void* vol, int itemsize, uint64_t nvox, uint32_t* out_dev);
+void launch_plane_events(hipStream_t s, const void* vol, int itemsize, int64_t planes, int64_t n1, int64_t n2, uint64_t* out_dev);
 void launch_pairs_collect(hipStream_t s, const PairTable& pt, uint64_t* out_keys, uint64_t* out_faces,
                           uint32_t* cursor);
 void launch_pairs_insert(hipStream_t s, const PairTable& pt, const uint64_t* keys, const uint64_t* faces,

@@ -19,11 +19,49 @@ INT32_MAX = np.iinfo(np.int32).max
 EMPTY_KEY = -1          # 0xFFFF...F as int64: padding entries of gathered pair lists
 
 
-def slab_range(n0, world, rank):
-    """Planes [lo, hi) of axis 0 owned by `rank` (contiguous, sizes differ by at most one)."""
+def slab_range(n0, world, rank, cuts=None):
+    """Planes [lo, hi) of axis 0 owned by `rank`: contiguous; equal plane counts (sizes differ by at most one) unless
+    `cuts` -- world + 1 plane indices from balanced_cuts -- says otherwise."""
+    if cuts is not None:
+        return int(cuts[rank]), int(cuts[rank + 1])
     base, rem = divmod(int(n0), int(world))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+# What a plane costs the sweep, in voxel-equivalents: its voxels stream at the HBM rate, every label change along the fast
+# axis is a record the sweep has to consume.  One record ~ EVENT_VOXELS voxels: C4, 1024^3 -- 0.73 ms of stream for 2^30
+# voxels, +0.36 ms for its 24.7 M run records and the faces that come with them (profiles/r04_NOTES.md) -- 0.36 / 24.7e6
+# against 0.73 / 2^30.
+EVENT_VOXELS = 21.0
+
+
+def plane_costs(events, plane_voxels, event_voxels=EVENT_VOXELS):
+    """float64[n0]: the cost model above for every plane of axis 0, from its count of label changes along the fast axis
+    (Context.plane_events() of a resident volume, or any estimate of it: a previous volume of a time series, a host-side
+    sample)."""
+    return float(plane_voxels) + float(event_voxels) * np.asarray(events, dtype=np.float64)
+
+
+def balanced_cuts(costs, world):
+    """world + 1 plane indices 0 = c[0] < c[1] < ... < c[world] = n0 that cut axis 0 into contiguous slabs of about equal
+    COST (the slowest slab sets the step: equal plane counts leave the emptier end slabs of a tissue waiting for the
+    middle ones).  Slab r ends at the first plane where the running cost reaches (r + 1) / world of the total; every slab
+    keeps at least one plane."""
+    costs = np.asarray(costs, dtype=np.float64)
+    n0, world = int(costs.shape[0]), int(world)
+    if world < 1 or n0 < world:
+        raise ValueError("cannot cut %d planes into %d slabs" % (n0, world))
+    run = np.cumsum(costs)
+    cuts = [0]
+    for r in range(1, world):
+        c = int(np.searchsorted(run, run[-1] * r / world, side="left")) + 1       # planes [0, c) hold >= r / world of the cost
+        # (closer of the two neighbouring cut positions to the target)
+        if c - 1 > cuts[-1] and abs(run[c - 2] - run[-1] * r / world) < abs(run[c - 1] - run[-1] * r / world):
+            c -= 1
+        cuts.append(min(max(c, cuts[-1] + 1), n0 - (world - r)))
+    cuts.append(n0)
+    return cuts
 
 
 # ------------------------------------------------------------------ device layout <-> ABI arrays
@@ -83,6 +121,38 @@ def allgather_pairs(keys, faces, group=None):
     dist.all_gather_into_tensor(kall, kpad, group=group)
     dist.all_gather_into_tensor(fall, fpad, group=group)
     return kall, fall, max(m, 1)
+
+
+def sums_shard_rows(nrows, world):
+    """Rows of the per-label sums every rank keeps after a reduce-scatter: the table is padded to world x this."""
+    return -(-int(nrows) // int(world))
+
+
+def reduce_scatter_sums(sums, shard, group=None):
+    """The per-label SUM as a reduce-scatter: `sums` int64[world * S, 10] (this rank's rows, zero padded) -> `shard`
+    int64[S, 10], the GLOBAL rows [rank * S, (rank + 1) * S).  Half the bytes of an all-reduce on every link -- nobody needs
+    all sums everywhere during a step (only the boxes decide which pairs travel); results gather the shards when asked for
+    (allgather_sums).  gloo has no reduce-scatter: there (CPU tests) an all-reduce of a copy, then the rank's rows."""
+    import torch.distributed as dist
+    rank = dist.get_rank(group)
+    S = shard.shape[0]
+    if dist.get_backend(group) == "nccl":
+        dist.reduce_scatter_tensor(shard, sums, op=dist.ReduceOp.SUM, group=group)
+    else:
+        tmp = sums.clone()
+        dist.all_reduce(tmp, op=dist.ReduceOp.SUM, group=group)
+        shard.copy_(tmp[rank * S:(rank + 1) * S])
+    return shard
+
+
+def allgather_sums(shard, nrows, group=None):
+    """COLLECTIVE: the global int64[nrows, 10] table from the ranks' shards."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    full = torch.empty((world * shard.shape[0],) + tuple(shard.shape[1:]), dtype=shard.dtype, device=shard.device)
+    dist.all_gather_into_tensor(full, shard.contiguous(), group=group)
+    return full[:nrows]
 
 
 # ------------------------------------------------------------------ halo hand-off between neighbours
@@ -173,9 +243,16 @@ class SlabJob(object):
     """
 
     def __init__(self, ctx, vol_tensor, itemsize, a_origin, has_low_halo, max_label, features,
-                 group=None, device=0, exchange_capacity=None, stream=None):
+                 group=None, device=0, exchange_capacity=None, stream=None, reduce="all"):
+        """reduce: "all" -- both tables all-reduced, every rank holds the global rows after step(); "scatter" -- the sums
+        (8 of the 10.4 MB at 100k labels) are reduce-SCATTERED: a rank keeps the global rows of its share of the labels in
+        `sums_shard` (and its own slab's partial rows in `sums`), only the boxes, which decide which pairs travel, are
+        all-reduced; result_counts() / result_arrays() gather the shards (collective)."""
         import torch
         self.ctx, self.vol, self.group = ctx, vol_tensor, group
+        if reduce not in ("all", "scatter"):
+            raise ValueError("reduce must be 'all' or 'scatter'")
+        self.reduce = reduce if group is not None else "all"
         # Kernels (C ABI) and collectives (torch.distributed) must be ordered on ONE stream: the torch stream given
         # here, else torch's current stream at construction -- never a private stream of the context, which nothing
         # orders against the stream RCCL enqueues on.
@@ -188,7 +265,15 @@ class SlabJob(object):
         self.a_origin = int(a_origin)           # global index of the first OWNED plane
         self.max_label, self.features = int(max_label), features
         dev = "cuda:%d" % device
-        self.sums = torch.zeros((self.max_label + 1, 10), dtype=torch.int64, device=dev)
+        rows = self.max_label + 1
+        self.sums_shard = None
+        if self.reduce == "scatter":
+            import torch.distributed as dist
+            world = dist.get_world_size(group)
+            S = sums_shard_rows(rows, world)
+            rows = world * S                            # (the rows past max_label stay zero: the sweep never writes them)
+            self.sums_shard = torch.zeros((S, 10), dtype=torch.int64, device=dev)
+        self.sums = torch.zeros((rows, 10), dtype=torch.int64, device=dev)
         self.boxes = torch.zeros((self.max_label + 1, 6), dtype=torch.int32, device=dev)
         ctx.set_volume_device(vol_tensor.data_ptr(), itemsize, vol_tensor.shape, a0_origin=a_origin,
                               has_low_halo=has_low_halo, keep=vol_tensor)
@@ -320,7 +405,11 @@ class SlabJob(object):
         first = adj and (self._cap is None or self._send is None)
         if first:
             self._agree_on_sizes()
-        allreduce_accumulators(self.sums, self.boxes, self.group)
+        if self.reduce == "scatter":
+            reduce_scatter_sums(self.sums, self.sums_shard, self.group)
+            dist.all_reduce(self.boxes, op=dist.ReduceOp.MIN, group=self.group)
+        else:
+            allreduce_accumulators(self.sums, self.boxes, self.group)
         self.ctx.accumulators_reduced()          # from here on a local re-run would lose the other ranks' rows
         if adj:
             if self._cap is None and not self._agree_on_capacity():
@@ -365,10 +454,18 @@ class SlabJob(object):
             self._step()
         raise RuntimeError("adjacency exchange still overflows after %d attempts" % 6)
 
+    def global_sums(self):
+        """The global int64[max_label + 1, 10] rows on this rank (COLLECTIVE after a reduce-scatter: gathers the shards)."""
+        if self.reduce == "scatter":
+            with self._on_stream():
+                return allgather_sums(self.sums_shard, self.max_label + 1, self.group)
+        return self.sums[:self.max_label + 1]
+
     def result_counts(self):
         self.finish()
+        sums = self.global_sums()
         self._torch.cuda.synchronize()
-        return self.sums[:, 0].cpu().numpy()
+        return sums[:, 0].cpu().numpy()
 
     def _global_pairs(self, plo, phi, faces):
         """COLLECTIVE: this context holds its private pairs + the merged travelling pairs (the same on every rank);
@@ -393,9 +490,10 @@ class SlabJob(object):
     def result_arrays(self):
         """Global result in the host-getter layout (memory-axis order)."""
         self.finish()
+        sums = self.global_sums()
         self._torch.cuda.synchronize()
         from . import _capi
-        out = from_device_layout(self.sums.cpu().numpy(), self.boxes.cpu().numpy(),
+        out = from_device_layout(sums.cpu().numpy(), self.boxes.cpu().numpy(),
                                  second_moments=bool(_capi.feature_mask(self.features) & _capi.F_MOMENT2))
         out["max_label"] = self.max_label
         if _capi.feature_mask(self.features) & _capi.F_ADJACENCY:
@@ -417,7 +515,7 @@ class PipelinedSlabJob(object):
     for and validates every step in flight, in issue order."""
 
     def __init__(self, vol_tensor, itemsize, a_origin, has_low_halo, max_label, features, group=None,
-                 device=0, depth=2, tile_planes=0):
+                 device=0, depth=2, tile_planes=0, reduce="all"):
         import torch
         from . import _capi
         torch.cuda.synchronize(device)            # the slab was written on another stream
@@ -429,7 +527,7 @@ class PipelinedSlabJob(object):
                 ctx.set_option(_capi.OPT_TILE_PLANES, tile_planes)
             with torch.cuda.stream(stream):
                 self.jobs.append(SlabJob(ctx, vol_tensor, itemsize, a_origin, has_low_halo, max_label, features,
-                                         group=group, device=device, stream=stream))
+                                         group=group, device=device, stream=stream, reduce=reduce))
         self._issued = 0
 
     @property
