@@ -33,3 +33,21 @@ def test_bench_line_has_the_contract_fields():
         assert k in c, k
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0
     assert abs(d["value"] - 96 * 128 * 512 / (d["ms_per_step"] * 1e-3) / 1e6) < 0.01 * d["value"]
+
+
+def test_bench_two_ranks_rehearsal_runs_the_multi_gpu_path():
+    """`bench.py --gpus 2` as the driver launches it, with two gloo ranks sharing this one GPU (TA_BENCH_BACKEND=gloo: RCCL
+    cannot put two ranks on one device): cost-balanced slab cuts, reduce-scattered sums, two steps in flight, ONE line from rank 0."""
+    env = dict(os.environ, TA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(29650 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dims", "96", "64", "512",
+                        "--steps", "3", "--warmup", "1", "--settle-ms", "5"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=900)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["per_label_reduce"] == "scatter"
+    cuts = d["config"]["slab_cuts"]
+    assert cuts[0] == 0 and cuts[-1] == 96 and len(cuts) == 3 and 0 < cuts[1] < 96
+    assert d["config"]["steps_in_flight"] == 2 and d["roofline"]["frac"] > 0 and "global_adjacency_gather_ms" in d["secondary"]

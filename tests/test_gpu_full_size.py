@@ -224,6 +224,14 @@ def test_c5_exchange_budget_eight_contexts_on_one_gpu(capsys):
     ctx0.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, keep=vol)
     ctx0.extract(_capi.F_ALL, L)
     whole = fetch(ctx0, L)
+    unsharded = []
+    for _ in range(3):
+        ctx0.extract(_capi.F_ALL, L)
+        unsharded.append(ctx0.timing()["ms_sweep"])
+    unsharded_ms = min(unsharded)
+    # the slabs are cut by COST (label changes per plane, one streaming pass), not by plane count: the slowest slab sets the step
+    events = ctx0.plane_events()
+    cuts = tad.balanced_cuts(tad.plane_costs(events, n1 * n2), 8)
     ctx0.close()
     plane_bytes = n1 * n2 * dtype.itemsize
     world = 8
@@ -233,9 +241,20 @@ def test_c5_exchange_budget_eight_contexts_on_one_gpu(capsys):
         a.record(); fn(); b.record(); b.synchronize()
         return a.elapsed_time(b)
 
+    def slab_sweep_ms(lo, hi):
+        halo = 1 if lo > 0 else 0
+        cx = dev.torch_context(0)
+        cx.set_volume_device(vol.data_ptr() + (lo - halo) * plane_bytes, dtype.itemsize, (hi - lo + halo, n1, n2), a0_origin=lo,
+                             has_low_halo=bool(halo), keep=vol)
+        cx.extract(_capi.F_ALL, L)
+        ms = min(timed(lambda: cx.extract(_capi.F_ALL, L)) for _ in range(3))
+        cx.close()
+        return ms
+    equal_ms = [slab_sweep_ms(*tad.slab_range(n0, world, r)) for r in range(world)]       # what equal plane counts give
+
     jobs, sweep_ms = [], []
     for r in range(world):
-        lo, hi = tad.slab_range(n0, world, r)
+        lo, hi = tad.slab_range(n0, world, r, cuts)
         halo = 1 if lo > 0 else 0
         ctx = dev.torch_context(0)
         sums = torch.zeros((L + 1, 10), dtype=torch.int64, device="cuda:0")
@@ -244,7 +263,7 @@ def test_c5_exchange_budget_eight_contexts_on_one_gpu(capsys):
                               has_low_halo=bool(halo), keep=vol)
         ctx.bind_accumulators(sums.data_ptr(), boxes.data_ptr(), L, keep=(sums, boxes))
         ctx.extract(_capi.F_ALL, L)                                   # warm-up: tables sized
-        sweep_ms.append(timed(lambda: ctx.extract(_capi.F_ALL, L)))
+        sweep_ms.append(min(timed(lambda: ctx.extract(_capi.F_ALL, L)) for _ in range(3)))
         jobs.append((ctx, sums, boxes, lo, hi))
     npairs = [j[0].adjacency_size() for j in jobs]
     # the two all-reduces, as torch ops on one device (the RCCL wire time is not measured here)
@@ -289,7 +308,13 @@ def test_c5_exchange_budget_eight_contexts_on_one_gpu(capsys):
     assert np.array_equal(keys[order], want_key) and np.array_equal(faces[order], whole["pair_faces"])
     for ctx, _, _, _, _ in jobs:
         ctx.close()
+    # (the imbalance term of DESIGN.md §6: with cost-balanced cuts the slowest slab is within a few per cent of the mean)
+    assert max(sweep_ms) / float(np.mean(sweep_ms)) < 1.08, (cuts, sweep_ms)
     with capsys.disabled():
+        print("\n[C5 as 8 slabs on one GPU] unsharded sweep %.3f ms; equal plane counts: slab sweep mean %.3f max %.3f ms (max / mean %.3f); "
+              "cost-balanced cuts %s: mean %.3f max %.3f ms (max / mean %.3f) -> unsharded / slowest slab = %.2fx"
+              % (unsharded_ms, float(np.mean(equal_ms)), max(equal_ms), max(equal_ms) / float(np.mean(equal_ms)), cuts,
+                 float(np.mean(sweep_ms)), max(sweep_ms), max(sweep_ms) / float(np.mean(sweep_ms)), unsharded_ms / max(sweep_ms)))
         print("\n[C5 as 8 slabs on one GPU, single-GPU estimate] per slab: sweep %.3f ms (max %.3f), local pairs %d..%d, "
               "travelling %d..%d of them (%.1f%%), all travelling pairs merged %d; pack_shared %.3f ms (max %.3f), "
               "merge_blocks of 8 blocks %.3f ms (max %.3f); rows to all-reduce %.1f MB; exchange block %.1f MB per rank"
