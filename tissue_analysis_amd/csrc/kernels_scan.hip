@@ -72,6 +72,7 @@ struct __attribute__((aligned(16))) ScanLds {
     uint32_t lbox[LSLOTS * 8];
     uint32_t lkeys[LSLOTS];
     uint32_t frame[4];                // origin (axes 0, 1, 2) of the tile-local coordinates: only the spill paths need it
+    uint32_t fcnt[2];                 // the flush: occupied label / pair slots (flush_tables gathers them first)
 #ifdef TA_LDS_PAD
     uint32_t pad_[TA_LDS_PAD];        // experiments only: fewer workgroups per CU
 #endif

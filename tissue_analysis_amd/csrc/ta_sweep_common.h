@@ -125,57 +125,73 @@ __device__ __forceinline__ void hot_row_init(const SweepArgs& A, const int tid) 
 
 // HOT = false compiles the hot-row path out (the naive cross-check kernel's rows; the sweep uses it for every mask).
 // RESET: every slot that held something is emptied again as it is read (the persistent kernel goes on with the next tile).
+//
+// DENSE flush.  A CU issues a global atomic wave-instruction about every 50 ns whatever the number of lanes that take part
+// (MI355X_MICROARCH.md), and a tile's tables are mostly empty -- ~38 of 128 label slots, ~120 of 512 pair slots on C4: walked
+// slot by slot, a flush issued ~60 such instructions a tile, most of them with a quarter of the lanes alive.  So the occupied
+// slots are first GATHERED into two lists (a ballot and an LDS counter per wave; the lists live in the record buffers of
+// waves 0 and 1, which nobody needs any more), and then the first K threads flush the K labels -- and the LAST K' threads
+// the K' pairs, so that the two kinds of global traffic start on different waves -- with every lane of an instruction alive.
 template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS, int NT = WAVES * 64, bool RESET = false>
 __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const int tid, const uint64_t A0,
                                              const uint64_t B0, const uint64_t C0, const uint32_t hot,
                                              const uint32_t wg) {
-    // The pairs first, as far as their first global round trip goes: the home slot of each of this thread's pairs in the
-    // device-global table is READ here and looked at after the labels' (fire-and-forget) atomics have been issued -- a
-    // tile's flush used to wait for a chain of global round trips per pair slot, two slots a thread, one after the other.
-    constexpr int PPT = ADJ ? (PSLOTS + NT - 1) / NT : 1;              // pair slots per thread
-    uint64_t fkey[PPT], fgk[PPT];
-    uint32_t fgh[PPT], ff0[PPT], ff1[PPT], ff2[PPT];
+    static_assert(LSLOTS * 2 <= (int)sizeof(S.wave[0].cql) + (int)sizeof(S.wave[0].cqc) && PSLOTS * 2 <= (int)sizeof(S.wave[1].cql) + (int)sizeof(S.wave[1].cqc),
+                  "the slot lists of the flush live in the run-record buffers of waves 0 and 1");
+    uint16_t* const llist = reinterpret_cast<uint16_t*>(&S.wave[0].cql[0]);
+    uint16_t* const plist = reinterpret_cast<uint16_t*>(&S.wave[1].cql[0]);
+    const int lane = tid & 63;
+    if (tid < 2) S.fcnt[tid] = 0u;
+    __syncthreads();
+    for (int i0 = 0; i0 < LSLOTS; i0 += NT) {
+        const int i = i0 + tid;
+        const bool live = i < LSLOTS && S.lkeys[i] != INVALID_LABEL;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(live);
+        uint32_t base = 0u;
+        if (lane == 0 && m) base = atomicAdd(&S.fcnt[0], (uint32_t)__builtin_popcountll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (live) llist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
+    }
     if (ADJ) {
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            const int i = tid + j * NT;
-            fkey[j] = i < PSLOTS ? S.pkeys[i] : EMPTY_KEY;
-            fgh[j] = 0u; fgk[j] = EMPTY_KEY; ff0[j] = ff1[j] = ff2[j] = 0u;
-            if (fkey[j] != EMPTY_KEY) {
-                fgh[j] = hash_pair((uint32_t)(fkey[j] >> 32), (uint32_t)fkey[j]) & A.pairs.mask;
-                fgk[j] = __hip_atomic_load(&A.pairs.keys[fgh[j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#if TA_PCNT64
-                const uint64_t c = S.pcnt[i];
-                ff0[j] = (uint32_t)(c & PCNT_MASK); ff1[j] = (uint32_t)((c >> PCNT_BITS) & PCNT_MASK); ff2[j] = (uint32_t)(c >> (2 * PCNT_BITS));
-#else
-                ff0[j] = S.pcnt[i * 3 + 0]; ff1[j] = S.pcnt[i * 3 + 1]; ff2[j] = S.pcnt[i * 3 + 2];
-#endif
-                if (RESET) {
-                    S.pkeys[i] = EMPTY_KEY;
-#if TA_PCNT64
-                    S.pcnt[i] = 0ull;
-#else
-                    S.pcnt[i * 3 + 0] = 0u; S.pcnt[i * 3 + 1] = 0u; S.pcnt[i * 3 + 2] = 0u;
-#endif
-                }
-            }
+        for (int i0 = 0; i0 < PSLOTS; i0 += NT) {
+            const int i = i0 + tid;
+            const bool live = i < PSLOTS && S.pkeys[i] != EMPTY_KEY;
+            const uint64_t m = __builtin_amdgcn_ballot_w64(live);
+            uint32_t base = 0u;
+            if (lane == 0 && m) base = atomicAdd(&S.fcnt[1], (uint32_t)__builtin_popcountll(m));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (live) plist[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)i;
         }
     }
-    uint64_t* const hot_rows = HOT ? hot_rows_of(A) : nullptr;
-    for (int i = tid; i < LSLOTS; i += NT) {
-        const uint32_t label = S.lkeys[i];
-        if (label == INVALID_LABEL) continue;
-        if (RESET) S.lkeys[i] = INVALID_LABEL;
-        if (label > A.max_label) {
-            atomicOr(&A.flags[FLAG_RANGE], 1u);
-            if (RESET) {
-#pragma unroll
-                for (int k = 0; k < NW; ++k) S.lsum[i * NW + k] = 0ull;
-                S.lbox[i * 8 + 0] = 0xFFFFFFFFu; S.lbox[i * 8 + 1] = 0xFFFFFFFFu; S.lbox[i * 8 + 2] = 0xFFFFFFFFu;
-                S.lbox[i * 8 + 3] = 0u; S.lbox[i * 8 + 4] = 0u; S.lbox[i * 8 + 5] = 0u;
-            }
-            continue;
+    __syncthreads();
+    const int nl = (int)S.fcnt[0], np = ADJ ? (int)S.fcnt[1] : 0;
+
+    // -- the pairs, from the last thread down: the home slot of the pair in the device-global table is READ first and looked
+    //    at afterwards (the first global round trip of the probe is in flight while the rest is prepared)
+    if (ADJ) {
+        for (int j = NT - 1 - tid; j < np; j += NT) {
+            const int i = plist[j];
+            const uint64_t key = S.pkeys[i];
+            const uint32_t lo = (uint32_t)(key >> 32), hi = (uint32_t)key;
+            const uint32_t gh = hash_pair(lo, hi) & A.pairs.mask;
+            const uint64_t gk = __hip_atomic_load(&A.pairs.keys[gh], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if TA_PCNT64
+            const uint64_t c = S.pcnt[i];
+            const uint32_t f0 = (uint32_t)(c & PCNT_MASK), f1 = (uint32_t)((c >> PCNT_BITS) & PCNT_MASK), f2 = (uint32_t)(c >> (2 * PCNT_BITS));
+            if (RESET) S.pcnt[i] = 0ull;
+#else
+            const uint32_t f0 = S.pcnt[i * 3 + 0], f1 = S.pcnt[i * 3 + 1], f2 = S.pcnt[i * 3 + 2];
+            if (RESET) { S.pcnt[i * 3 + 0] = 0u; S.pcnt[i * 3 + 1] = 0u; S.pcnt[i * 3 + 2] = 0u; }
+#endif
+            if (RESET) S.pkeys[i] = EMPTY_KEY;
+            pair_add_global_from(A.pairs, lo, hi, f0, f1, f2, A.flags, gh, gk);
         }
+    }
+    // -- the labels, from the first thread up
+    uint64_t* const hot_rows = HOT ? hot_rows_of(A) : nullptr;
+    for (int j = tid; j < nl; j += NT) {
+        const int i = llist[j];
+        const uint32_t label = S.lkeys[i];
         const uint64_t w0 = S.lsum[i * NW + 0], w1 = S.lsum[i * NW + 1];
         LocalSums L;
         L.n = w0 & 0xffffffffull; L.sb = w0 >> 32; L.sa = w1 & 0xffffffffull; L.sc = w1 >> 32;
@@ -187,6 +203,16 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
         } else {
             L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
         }
+        const uint32_t bx0 = S.lbox[i * 8 + 0], bx1 = S.lbox[i * 8 + 1], bx2 = S.lbox[i * 8 + 2];
+        const uint32_t bx3 = S.lbox[i * 8 + 3], bx4 = S.lbox[i * 8 + 4], bx5 = S.lbox[i * 8 + 5];
+        if (RESET) {
+            S.lkeys[i] = INVALID_LABEL;
+#pragma unroll
+            for (int k = 0; k < NW; ++k) S.lsum[i * NW + k] = 0ull;
+            S.lbox[i * 8 + 0] = 0xFFFFFFFFu; S.lbox[i * 8 + 1] = 0xFFFFFFFFu; S.lbox[i * 8 + 2] = 0xFFFFFFFFu;
+            S.lbox[i * 8 + 3] = 0u; S.lbox[i * 8 + 4] = 0u; S.lbox[i * 8 + 5] = 0u;
+        }
+        if (label > A.max_label) { atomicOr(&A.flags[FLAG_RANGE], 1u); continue; }
         uint64_t g[NSUM];
         local_to_global(L, A0, B0, C0, g);
         // the hot label goes to this workgroup's private row: same atomics, nobody to contend with
@@ -196,22 +222,9 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
 #pragma unroll
         for (int k = 0; k < (MOM2 ? NSUM : 4); ++k) atomicAdd(row + k, (unsigned long long)g[k]);
         int32_t* box = priv ? reinterpret_cast<int32_t*>(hr + NSUM) : &A.boxes[(uint64_t)label * NBOX];
-        atomicMin(box + 0, (int32_t)(A0 + S.lbox[i * 8 + 0])); atomicMin(box + 3, -(int32_t)(A0 + S.lbox[i * 8 + 3]));
-        atomicMin(box + 1, (int32_t)(B0 + S.lbox[i * 8 + 1])); atomicMin(box + 4, -(int32_t)(B0 + S.lbox[i * 8 + 4]));
-        atomicMin(box + 2, (int32_t)(C0 + S.lbox[i * 8 + 2])); atomicMin(box + 5, -(int32_t)(C0 + S.lbox[i * 8 + 5]));
-        if (RESET) {
-#pragma unroll
-            for (int k = 0; k < NW; ++k) S.lsum[i * NW + k] = 0ull;
-            S.lbox[i * 8 + 0] = 0xFFFFFFFFu; S.lbox[i * 8 + 1] = 0xFFFFFFFFu; S.lbox[i * 8 + 2] = 0xFFFFFFFFu;
-            S.lbox[i * 8 + 3] = 0u; S.lbox[i * 8 + 4] = 0u; S.lbox[i * 8 + 5] = 0u;
-        }
-    }
-    if (ADJ) {
-#pragma unroll
-        for (int j = 0; j < PPT; ++j) {
-            if (fkey[j] != EMPTY_KEY)
-                pair_add_global_from(A.pairs, (uint32_t)(fkey[j] >> 32), (uint32_t)fkey[j], ff0[j], ff1[j], ff2[j], A.flags, fgh[j], fgk[j]);
-        }
+        atomicMin(box + 0, (int32_t)(A0 + bx0)); atomicMin(box + 3, -(int32_t)(A0 + bx3));
+        atomicMin(box + 1, (int32_t)(B0 + bx1)); atomicMin(box + 4, -(int32_t)(B0 + bx4));
+        atomicMin(box + 2, (int32_t)(C0 + bx2)); atomicMin(box + 5, -(int32_t)(C0 + bx5));
     }
 }
 
