@@ -22,7 +22,8 @@ procs, objs = [], []
 for src in B.SOURCES:
     o = os.path.join(out_dir, src.replace(".hip", ".o"))
     objs.append(o)
-    cmd = [hipcc] + B.FLAGS + B.EXTRA_FLAGS.get(src, []) + defs + ["-c", os.path.join(B.CSRC, src), "-o", o]
+    extra = [] if "--no-extra-flags" in sys.argv else B.EXTRA_FLAGS.get(src, [])        # (e.g. machine LICM back on)
+    cmd = [hipcc] + B.FLAGS + extra + defs + ["-c", os.path.join(B.CSRC, src), "-o", o]
     if src == "kernels_scan.hip":
         cmd += ["-save-temps=obj", "-Rpass-analysis=kernel-resource-usage"]
     procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, cwd=out_dir)))

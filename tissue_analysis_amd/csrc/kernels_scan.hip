@@ -664,10 +664,13 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #ifndef TA_DRAIN_ALL
 #define TA_DRAIN_ALL 1
 #endif
+#ifndef TA_DRAIN_ALL_U16
+#define TA_DRAIN_ALL_U16 0    // the full tiles of uint16 volumes too (their kernel sits at 125 VGPRs: see the build's register check)
+#endif
 #ifndef TA_FDRAIN
 #define TA_FDRAIN 128         // face records in the buffer from which the top-of-plane drain takes the full groups
 #endif
-    constexpr bool DRAIN_ALL = ADJ && TA_DRAIN_ALL && FCAP % 64 == 0 && RCAP % 64 == 0 && sizeof(T) == 4 && RB == 2 && !EDGE;
+    constexpr bool DRAIN_ALL = ADJ && TA_DRAIN_ALL && FCAP % 64 == 0 && RCAP % 64 == 0 && (TA_DRAIN_ALL_U16 || sizeof(T) == 4) && RB == 2 && !EDGE;
 
     const T* vol = reinterpret_cast<const T*>(A.vol);
     const int64_t n1 = A.n1, n2 = A.n2, plane = n1 * n2;
