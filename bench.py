@@ -286,8 +286,8 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = nvox * args.steps / dt / 1e6
 
+    labels_present = int((job.result_counts() > 0).sum())       # (COLLECTIVE when the sums are reduce-scattered: every rank asks)
     if rank == 0:
-        labels_present = int((job.result_counts() > 0).sum())
         sweep = float(np.mean(sweep_ms))
         achieved = bytes_read / (sweep * 1e-3) / 1e9
         owned = job.owned_view()

@@ -42,7 +42,7 @@ def test_bench_two_ranks_rehearsal_runs_the_multi_gpu_path():
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(29650 + os.getpid() % 300), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dims", "96", "64", "512",
                         "--steps", "3", "--warmup", "1", "--settle-ms", "5"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
-                       stderr=subprocess.PIPE, timeout=900)
+                       stderr=subprocess.PIPE, timeout=300)
     assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
     lines = [l for l in p.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1
