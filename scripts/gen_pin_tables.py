@@ -15,7 +15,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tissue_analysis_amd", "csrc", "ta_pin_tables.inc")
 TABLES = [(104, True), (120, True), (76, False), (80, False)]      # (first pinned register, with adjacency)
-TWO_ROW_TABLES = [82]           # adjacency, TWO rows per wave only: 13 registers (rows, row above, voxel to the left)
+TWO_ROW_TABLES = [82, 112]      # adjacency, TWO rows per wave only: 13 registers (rows, row above, voxel to the left); 112: the padded tiles
 
 
 def clobbers(base, n):

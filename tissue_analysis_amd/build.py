@@ -51,7 +51,7 @@ def _check_pinned(hipcc, verbose=False):
     subprocess.check_call(cmd, cwd=OBJDIR)
     bases = {}
     for line in open(os.path.join(CSRC, "kernels_scan.hip")):
-        m = re.match(r"#define TA_PIN_(ADJ_PAD|MOM_PAD|ADJ2|ADJ|MOM) (\d+)", line)
+        m = re.match(r"#define TA_PIN_(ADJ2_PAD|ADJ_PAD|MOM_PAD|ADJ2|ADJ|MOM) (\d+)", line)
         if m:
             bases[m.group(1)] = int(m.group(2))
     reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
@@ -73,6 +73,8 @@ def _check_pinned(hipcc, verbose=False):
                 continue              # edge kernels issue no hand-pinned loads: any register is theirs
             if "scan_noadj_pad_kernel" in func:
                 ranges = [bases["MOM_PAD"]]
+            elif "scan_pad2_kernel" in func:
+                ranges = [bases["ADJ2_PAD"]]
             elif "scan_pad_kernel" in func:
                 ranges = [bases["ADJ_PAD"]]
             elif "scan_noadj_kernel" in func:
@@ -88,7 +90,7 @@ def _check_pinned(hipcc, verbose=False):
                 if any(hi >= b and lo < b + 21 for b in ranges):      # (21 pinned with adjacency, 16 without: the wider check is safe)
                     bad.append("%s:%d: %s" % (func, ln, t))
                     break
-    if bad or len(bases) != 5:
+    if bad or len(bases) != 6:
         raise RuntimeError("compiler-allocated VGPRs reach the hand-pinned registers in kernels_scan.hip:\n  %s"
                            % "\n  ".join(bad[:10]))
 

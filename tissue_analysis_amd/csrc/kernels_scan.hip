@@ -634,8 +634,12 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define TA_PIN_MOM_PAD 80
 #define TA_CAP_ADJ_PAD 116
 #define TA_CAP_MOM_PAD 76
+// ... and with two rows per wave (uint32 volumes with adjacency) the landing zone is 13 registers: 112 + 13 = 125, FOUR waves
+// per SIMD for the partial tiles (1000^3 is a quarter partial tiles; real volumes are rarely multiples of 8 x 256)
+#define TA_PIN_ADJ2_PAD 112
+#define TA_CAP_ADJ2_PAD 108
 template <int BASE> struct Pin;
-#include "ta_pin_tables.inc"        // Pin<104>, Pin<120>, Pin<76>, Pin<80>: generated by scripts/gen_pin_tables.py
+#include "ta_pin_tables.inc"        // Pin<104>, Pin<120>, Pin<76>, Pin<80>, Pin<82>, Pin<112>: generated by scripts/gen_pin_tables.py
 template <typename T, int VPL>
 __device__ __forceinline__ void unpack_strip(const u32x4& x, uint32_t (&dst)[VPL]) {
     if (sizeof(T) == 4) {
@@ -1275,6 +1279,11 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_
     scan_kernel_body<T, VPL, RB, true, MOM2, true, TA_PIN_ADJ_PAD>(A, sp, wg0);
 }
 template <typename T, int VPL, int RB, bool MOM2>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ2_PAD))) scan_pad2_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+    static_assert(RB == 2 && sizeof(T) == 4, "the 13-register landing zone holds two rows of a uint32 volume");
+    scan_kernel_body<T, VPL, RB, true, MOM2, true, TA_PIN_ADJ2_PAD>(A, sp, wg0);
+}
+template <typename T, int VPL, int RB, bool MOM2>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_MOM_PAD))) scan_noadj_pad_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
     scan_kernel_body<T, VPL, RB, false, MOM2, true, TA_PIN_MOM_PAD>(A, sp, wg0);
 }
@@ -1297,8 +1306,12 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_star
         } else {
             if (n_in) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
         }
-        if (n_ed && sp.padded) hipExtLaunchKernelGGL((scan_pad_kernel<T, VPL, RB, MOM2>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
-        else if (n_ed) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
+        if constexpr (sizeof(T) == 4 && RB == 2) {
+            if (n_ed && sp.padded) hipExtLaunchKernelGGL((scan_pad2_kernel<T, VPL, RB, MOM2>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
+        } else {
+            if (n_ed && sp.padded) hipExtLaunchKernelGGL((scan_pad_kernel<T, VPL, RB, MOM2>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
+        }
+        if (n_ed && !sp.padded) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
     } else {
         if (n_in) hipExtLaunchKernelGGL((scan_noadj_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
         if (n_ed && sp.padded) hipExtLaunchKernelGGL((scan_noadj_pad_kernel<T, VPL, RB, MOM2>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
