@@ -247,6 +247,17 @@ TA_API int ta_wall_voxels_get(ta_ctx* ctx, uint32_t* pairs /* [n][2] */, int32_t
  * in memory order -- what wall_voxels_between_two_cells / _per_cell / _per_cells_pairs look up (SIA:759-880). */
 TA_API int ta_wall_voxels_get_by_pair(ta_ctx* ctx, uint32_t* pairs /* [n][2] */, int32_t* coords /* [n][3] */, double* ms);
 
+/* The median voxel of every wall, computed on the device (TGI:210-242 through SIA:1586-1635; new in TA_ABI_VERSION 3, the
+ * reference has no native interface to mirror): after ta_wall_voxels_count, ta_wall_medians groups the records by pair on
+ * the device, runs the reference's Weiszfeld iteration (its start, its stopping rule, IEEE double sums in record order: the
+ * arithmetic of tissue_analysis_amd/geometry.py::weiszfeld_segments) on every wall -- one thread a wall --, truncates the
+ * position and picks the wall voxel nearest to it (the first one on ties).  *nwalls = number of walls E; the results stay
+ * on the context until the volume changes.  ta_wall_medians_get copies them out, sorted by (lo, hi): pairs u32[E][2], the
+ * walls' voxel counts u32[E], the median voxels i32[E][3] in array-axis order.  TA_EINVAL when a wall is still moving after
+ * max_iter passes (the reference raises there).  Volumes in memory (C) order only: the order of a wall's voxels decides ties. */
+TA_API int ta_wall_medians(ta_ctx* ctx, int max_iter, int64_t* nwalls, double* ms_kernels);
+TA_API int ta_wall_medians_get(ta_ctx* ctx, uint32_t* pairs, uint32_t* sizes, int32_t* medians);
+
 /* ---- stream-ordered adjacency exchange (no host round trip) ------------------
  * One exchange block per rank, uint64 words, TA_EXCHANGE_WORDS(capacity) long:
  *   [0] pair count (may exceed capacity)  [1] status bits  [2..2+cap) keys, ~0 padded

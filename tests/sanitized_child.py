@@ -55,6 +55,8 @@ def walk_c_abi():
         "ta_wall_voxels_count": (None, ctypes.byref(i64)),
         "ta_wall_voxels_get": (None, buf, buf, ctypes.byref(dbl)),
         "ta_wall_voxels_get_by_pair": (None, buf, buf, ctypes.byref(dbl)),
+        "ta_wall_medians": (None, 10, ctypes.byref(i64), None),
+        "ta_wall_medians_get": (None, buf, buf, buf),
         "ta_extract": (None, 31, 10),
         "ta_get_labels": (None, buf, buf, buf, buf),
         "ta_adjacency_size": (None, ctypes.byref(i64)),

@@ -94,6 +94,49 @@ def test_c2_full_size_against_the_c_oracle():
     assert 2000 < int((want["count"] > 0).sum()) <= 5001
 
 
+def test_c2_wall_medians_end_to_end_on_the_device(capsys):
+    """`graph_from_image(..., 'wall_median')` at C2's size (512^3 uint16, 15 M wall-voxel records): the medians of all ~16 k walls
+    are computed on the device from the records it grouped by pair and E x 3 integers come back (rounds 2-3: 300 MB of
+    records to pageable host memory, then Weiszfeld on the host).  Checked against the host arithmetic on a sample of the
+    walls; the end-to-end times of both routes are printed."""
+    import time
+    import torch
+    from tissue_analysis_amd import SpatialImageAnalysis3D, geometry, graph_from_image
+    c = synth.CONFIGS["C2"]
+    dims, dtype = c["dims"], np.dtype(c["dtype"])
+    ctx = dev.torch_context(0)
+    vol, L = dev.synth_slab(ctx, dims, dtype, c["n_cells"], c["seed"])
+    torch.cuda.synchronize()
+    host = vol.cpu().numpy().view(dtype)
+    ctx.close()
+    del vol
+    sia = SpatialImageAnalysis3D(host, ignoredlabels=0, background=1)
+    t0 = time.perf_counter()
+    g = graph_from_image(sia, spatio_temporal_properties=['wall_median'], background=1, ignore_cells_at_stack_margins=False)
+    t_dev = time.perf_counter() - t0
+    assert sia._walls is None and sia._wall_medians
+    keys, sizes, med = sia._wall_medians
+    kernels_ms = sia._resident().ms["wall_medians"]
+    # a sample of the walls against the host arithmetic on the grouped records
+    t0 = time.perf_counter()
+    table = sia.wall_table()
+    t_fetch = time.perf_counter() - t0
+    pick = np.unique(np.linspace(0, keys.size - 1, 400).astype(np.int64))
+    at = np.searchsorted(table.pairs, keys[pick])
+    assert np.array_equal(table.pairs[at], keys[pick]) and np.array_equal(table.stop[at] - table.start[at], sizes[pick].astype(np.int64))
+    rows, seg = geometry.gather_segments(table.start[at], table.stop[at])
+    want = geometry.median_voxels(table.coords[rows].astype(np.int64), seg).reshape(-1, 3)
+    assert np.array_equal(med[pick], want)
+    t0 = time.perf_counter()
+    geometry.median_voxels(table.coords.astype(np.int64), (table.stop - table.start))
+    t_host = time.perf_counter() - t0
+    with capsys.disabled():
+        print("\n[C2 wall medians: %d walls, %d wall-voxel records] graph_from_image(..., 'wall_median') end to end %.1f ms with the medians "
+              "on the device (group by pair + one thread a wall: %.2f ms of kernels); the route of rounds 2-3: %.1f ms to fetch the grouped "
+              "records + %.1f ms of host arithmetic" % (keys.size, int(sizes.sum()), t_dev * 1e3, kernels_ms, t_fetch * 1e3, t_host * 1e3))
+    assert len(g.edge_property('wall_median')) > 10000
+
+
 def test_c4_tissue_filled_full_size_against_the_c_oracle(capsys):
     """The volume bench.py's `secondary.tissue_filled` times: no ellipsoid, every one of the ~50k cells present."""
     import time

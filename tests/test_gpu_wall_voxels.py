@@ -136,3 +136,51 @@ def test_degenerate_and_ragged_shapes(shape):
                     want = ref.wall_voxels_between_two_cells(a, b)
                     got = sia.wall_voxels_between_two_cells(a, b)
                     assert got.shape == want.shape and np.array_equal(got, want), (shape, dtype, a, b)
+
+
+def _flat_symmetric_walls():
+    """Cuboid cells: flat walls whose geometric median sits ON integer coordinates -- the truncation that follows the Weiszfeld
+    iteration is then decided by the last bit of sums that must be taken in the reference's order."""
+    v = np.ones((20, 24, 40), dtype=np.uint16)
+    v[2:10, 2:11, 3:20] = 2
+    v[10:18, 2:11, 3:20] = 3
+    v[2:10, 11:21, 3:20] = 4
+    v[10:18, 11:21, 3:21] = 5
+    v[2:18, 2:21, 21:37] = 6
+    return v
+
+
+@pytest.mark.parametrize("make", [lambda: voronoi((36, 40, 44), 40, 71, np.uint16), lambda: voronoi((30, 28, 260), 50, 72, np.uint32),
+                                  _flat_symmetric_walls, lambda: random_blocks((14, 18, 30), 60, 73, np.uint32)],
+                         ids=["voronoi_u16", "voronoi_u32", "flat_symmetric", "blocks_u32"])
+def test_wall_medians_on_the_device_equal_the_host_arithmetic(gpu_ctx, make):
+    """ta_wall_medians (one thread a wall: the reference's Weiszfeld rules in IEEE double, sums in record order, truncation,
+    nearest wall voxel) against geometry.median_voxels on the records the device grouped by pair: the same voxel for EVERY wall."""
+    from tissue_analysis_amd import geometry
+    vol = make()
+    gpu_ctx.set_volume(vol)
+    keys, sizes, med, ms = gpu_ctx.wall_medians()
+    lo, hi, coords, _ = gpu_ctx.wall_voxels(by_pair=True)
+    k = (lo.astype(np.uint64) << np.uint64(32)) | hi.astype(np.uint64)
+    uk, first, count = np.unique(k, return_index=True, return_counts=True)
+    assert np.array_equal(keys, uk) and np.array_equal(sizes, count.astype(np.uint32)) and np.all(first == np.cumsum(count) - count)
+    want = geometry.median_voxels(coords.astype(np.int64), count)
+    assert np.array_equal(med.astype(np.int64), want.reshape(-1, 3)), int((med != want.reshape(-1, 3)).any(axis=1).sum())
+    assert ms > 0 and keys.size > 5
+
+
+def test_graph_wall_medians_take_the_device_path():
+    """graph_from_image(..., 'wall_median') on an analysis that holds nothing but its resident volume: the medians come from
+    ta_wall_medians (no wall table is pulled to the host) and equal the host arithmetic on the wall table."""
+    from tissue_analysis_amd import SpatialImageAnalysis3D, graph_from_image
+    vol = voronoi((30, 34, 40), 30, 74, np.uint16)
+    sia = SpatialImageAnalysis3D(vol, ignoredlabels=0, background=1)
+    g = graph_from_image(sia, spatio_temporal_properties=['wall_median'], background=1, ignore_cells_at_stack_margins=False)
+    assert sia._walls is None and sia._wall_medians                        # the device answered; no table on the host
+    sia2 = SpatialImageAnalysis3D(vol, ignoredlabels=0, background=1)
+    sia2.wall_table()                                                       # a table on the host: the host arithmetic answers
+    g2 = graph_from_image(sia2, spatio_temporal_properties=['wall_median'], background=1, ignore_cells_at_stack_margins=False)
+    a, b = g.edge_property('wall_median'), g2.edge_property('wall_median')
+    assert len(a) > 20 and dict(a.items()) == dict(b.items())
+    for name in ('epidermis_wall_median', 'unlabelled_wall_median'):
+        assert dict(g.vertex_property(name).items()) == dict(g2.vertex_property(name).items())

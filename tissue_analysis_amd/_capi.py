@@ -29,6 +29,7 @@ SYMBOLS = (
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_get_option", "ta_ctx_synchronize", "ta_volume_set",
     "ta_volume_set_device", "ta_volume_max_label", "ta_volume_plane_events", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
     "ta_volume_first_layer", "ta_volume_hollow", "ta_volume_layer18", "ta_wall_voxels_count", "ta_wall_voxels_get", "ta_wall_voxels_get_by_pair",
+    "ta_wall_medians", "ta_wall_medians_get",
     "ta_extract", "ta_get_labels",
     "ta_adjacency_size", "ta_adjacency_get", "ta_timing", "ta_timing_series", "ta_read_probe", "ta_debug_counters", "ta_bind_accumulators",
     "ta_accumulators_device", "ta_accumulators_reduced", "ta_adjacency_device", "ta_adjacency_export", "ta_adjacency_merge",
@@ -95,6 +96,8 @@ def load():
         "ta_volume_layer18": (ci, [vp, vp]),
         "ta_wall_voxels_count": (ci, [vp, P(i64)]),
         "ta_wall_voxels_get": (ci, [vp, vp, vp, P(ctypes.c_double)]),
+        "ta_wall_medians": (ci, [vp, ci, P(i64), P(ctypes.c_double)]),
+        "ta_wall_medians_get": (ci, [vp, vp, vp, vp]),
         "ta_wall_voxels_get_by_pair": (ci, [vp, vp, vp, P(ctypes.c_double)]),
         "ta_extract": (ci, [vp, u32, u32]),
         "ta_get_labels": (ci, [vp, vp, vp, vp, vp]),
@@ -301,6 +304,28 @@ class Context(object):
         fetch = self._lib.ta_wall_voxels_get_by_pair if by_pair else self._lib.ta_wall_voxels_get
         _check(fetch(self._h, pairs.ctypes.data, coords.ctypes.data, ctypes.byref(ms)))
         return pairs[:, 0], pairs[:, 1], coords, ms.value
+
+    def wall_medians(self, max_iter=200):
+        """The median voxel of every wall of the resident volume, computed on the device (C-ordered volumes): keys
+        uint64[E] = lo << 32 | hi ascending, sizes uint32[E] (wall voxels), medians int32[E, 3] (array-axis order), and
+        the kernels' milliseconds (grouping by pair included).  Raises ValueError where the reference does: a wall still
+        moving after `max_iter` Weiszfeld passes."""
+        n = ctypes.c_int64(0)
+        _check(self._lib.ta_wall_voxels_count(self._h, ctypes.byref(n)))
+        count, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
+        try:
+            _check(self._lib.ta_wall_medians(self._h, int(max_iter), ctypes.byref(count), ctypes.byref(ms)))
+        except TissueScanError as e:
+            if e.code == TA_EINVAL and "still moving" in str(e):
+                raise ValueError(str(e))
+            raise
+        E = count.value
+        pairs = np.empty((E, 2), dtype=np.uint32)
+        sizes = np.empty(E, dtype=np.uint32)
+        med = np.empty((E, 3), dtype=np.int32)
+        _check(self._lib.ta_wall_medians_get(self._h, pairs.ctypes.data, sizes.ctypes.data, med.ctypes.data))
+        keys = (pairs[:, 0].astype(np.uint64) << np.uint64(32)) | pairs[:, 1].astype(np.uint64)
+        return keys, sizes, med, ms.value
 
     def set_volume_device(self, dev_ptr, itemsize, buf_dims, a0_origin=0, has_low_halo=False, keep=None):
         _check(self._lib.ta_volume_set_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(itemsize),

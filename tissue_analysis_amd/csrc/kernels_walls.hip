@@ -605,6 +605,8 @@ __global__ void __launch_bounds__(256) wall_scan_apply_kernel(const uint32_t* co
 // the same three kernels as a general exclusive scan of uint32 counts (the adjacency sort buckets its pairs with it)
 uint64_t scan_u32_scratch_bytes(uint64_t n) { return ((n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK + 1) * 8 + 16; }
 
+uint64_t* scan_u32_total(void* scratch, uint64_t n) { return (uint64_t*)scratch + (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK; }
+
 void launch_scan_u32_exclusive(hipStream_t s, const uint32_t* counts, uint64_t n, void* scratch, uint64_t* offsets) {
     if (n == 0) return;
     const uint64_t blocks = (n + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;

@@ -106,6 +106,8 @@ struct ta_ctx {
     DevBuf wall_stage;                                  // wall voxels: the records the count pass staged (kept until the volume changes)
     int64_t wall_records = -1;                          // result of the last ta_wall_voxels_count, -1 = none
     uint32_t wall_region = 0, wall_not_staged = 0;      // records per staging region of that call (0 = nothing staged); cells left to the second walk
+    DevBuf wall_medians;                                // ta_wall_medians: pairs u32[E][2] | sizes u32[E] | medians i32[E][3]
+    int64_t wall_median_count = -1;                     // E of the last ta_wall_medians, -1 = none
     bool wall_wide = false;                             // that call met a label >= 2^31
     uint32_t wall_label_or = 0;                         // OR of all labels of the volume (that call): the bits a label takes
     double wall_ms = 0.0;
@@ -367,6 +369,7 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     c->hot_rows.release(); c->sort_buf.release(); c->h_pairs.release();
     c->wall_counts.release();
     c->wall_stage.release();
+    c->wall_medians.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ring) if (e) (void)hipEventDestroy(e);
@@ -487,6 +490,7 @@ TA_API int ta_volume_set(ta_ctx* c, const void* host_ptr, int itemsize, const in
     c->vol = c->owned_vol.p;
     c->auto_tile_shift = 0;
     c->wall_records = -1;
+    c->wall_median_count = -1;
     c->wall_stage.release();
     c->itemsize = itemsize;
     for (int k = 0; k < 3; ++k) { c->perm[k] = perm[k]; c->mdims[k] = dims[perm[k]]; }
@@ -509,6 +513,7 @@ TA_API int ta_volume_set_device(ta_ctx* c, const void* dev_ptr, int itemsize, co
     c->volume_slack = 0;
     c->auto_tile_shift = 0;
     c->wall_records = -1;
+    c->wall_median_count = -1;
     c->wall_stage.release();
     c->itemsize = itemsize;
     for (int k = 0; k < 3; ++k) { c->perm[k] = k; c->mdims[k] = buf_dims[k]; }
@@ -540,6 +545,7 @@ TA_API int ta_volume_relabel(ta_ctx* c, const uint32_t* lut, uint32_t lut_len) {
     d.release();
     if (e != hipSuccess) return fail(TA_EHIP, "relabel: %s", hipGetErrorString(e));
     c->extracted = c->checked = false;
+    c->wall_median_count = -1;
     c->wall_records = -1;           // the staged wall records carry the OLD labels: a fetch must ask for a fresh count
     c->wall_region = 0; c->wall_not_staged = 0;
     return TA_OK;
@@ -724,6 +730,7 @@ TA_API int ta_wall_voxels_count(ta_ctx* c, int64_t* nrecords) {
     if (e1) (void)hipEventDestroy(e1);
     if (e != hipSuccess) return fail(TA_EHIP, "wall voxel count: %s", hipGetErrorString(e));
     c->wall_records = (int64_t)line.total;
+    c->wall_median_count = -1;
     c->wall_not_staged = line.not_staged;
     c->wall_wide = wide;
     c->wall_label_or = line.label_or;
@@ -736,16 +743,11 @@ TA_API int ta_wall_voxels_count(ta_ctx* c, int64_t* nrecords) {
 }
 
 namespace {
-int wall_voxels_fetch(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_out, bool by_pair) {
-    if (!c) return fail(TA_EINVAL, "ctx is NULL");
-    if (c->wall_records < 0) return fail(TA_EINVAL, "call ta_wall_voxels_count first");
-    int rc = use_device(c);
-    if (rc != TA_OK) return rc;
+// The records of the last ta_wall_voxels_count on the DEVICE, in memory order or grouped by pair: `buf` owns them, *pairs_dev /
+// *coords_dev point into it; the launches are bracketed by e0 / e1 when given.  Only enqueues work (and allocates).
+int wall_records_device(ta_ctx* c, bool by_pair, DevBuf& buf, uint32_t** pairs_dev, int32_t** coords_dev, hipEvent_t e0, hipEvent_t e1) {
     const uint64_t n = (uint64_t)c->wall_records;
-    if (ms_out) *ms_out = c->wall_ms;
-    if (n == 0) return TA_OK;
-    if (!pairs || !coords) return fail(TA_EINVAL, "NULL output array");
-    if (by_pair && n >= (1ull << 32)) return fail(TA_EINVAL, "too many records (%llu) for the grouped fetch", (unsigned long long)n);
+    int rc;
     const ta::WallPlan plan = ta::wall_plan(c->mdims[0], c->mdims[1], c->mdims[2]);
     ta::WallBuffers wb;
     (void)wall_bufs(c->wall_counts.p, plan, wb);
@@ -754,18 +756,14 @@ int wall_voxels_fetch(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_ou
     // one allocation: records in memory order | (grouped fetch) the same again grouped, sort keys / indices x 2, sort temp
     const uint64_t temp_bytes = by_pair ? ta::wall_sort_temp_bytes(n) : 0;
     const uint64_t rec = n * 8, co = (n * 12 + 15) & ~15ull, ix = (n * 4 + 15) & ~15ull;
-    DevBuf buf;
     if ((rc = buf.reserve(by_pair ? 2 * rec + 2 * co + 2 * rec + 2 * ix + temp_bytes + 64 : rec + co)) != TA_OK) return rc;
     char* p = (char*)buf.p;
     uint32_t* dpa = (uint32_t*)p; p += rec;
     int32_t* dco = (int32_t*)p; p += co;
     uint32_t* gpa = dpa; int32_t* gco = dco;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    hipError_t e = hipEventCreate(&e0);
-    if (e == hipSuccess) e = hipEventCreate(&e1);
-    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    hipError_t e = e0 ? hipEventRecord(e0, c->stream) : hipSuccess;
     if (e == hipSuccess) {
-        // records leave the kernels as (lo, hi) / coordinates in ARRAY-axis order: straight into the caller's arrays
+        // records leave the kernels as (lo, hi) / coordinates in ARRAY-axis order
         ta::launch_wall_fetch(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], wb, c->wall_wide,
                               c->wall_not_staged, dpa, dco, c->perm);
         e = hipGetLastError();
@@ -781,7 +779,33 @@ int wall_voxels_fetch(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_ou
         while (label_bits < 32 && (c->wall_label_or >> label_bits) != 0u) ++label_bits;
         e = ta::launch_wall_group_by_pair(c->stream, dpa, dco, n, k0, k1, i0, i1, p, temp_bytes, label_bits, gpa, gco);
     }
-    if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+    if (e == hipSuccess && e1) e = hipEventRecord(e1, c->stream);
+    if (e != hipSuccess) return fail(TA_EHIP, "wall voxels: %s", hipGetErrorString(e));
+    *pairs_dev = gpa; *coords_dev = gco;
+    return TA_OK;
+}
+
+int wall_voxels_fetch(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_out, bool by_pair) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if (c->wall_records < 0) return fail(TA_EINVAL, "call ta_wall_voxels_count first");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t n = (uint64_t)c->wall_records;
+    if (ms_out) *ms_out = c->wall_ms;
+    if (n == 0) return TA_OK;
+    if (!pairs || !coords) return fail(TA_EINVAL, "NULL output array");
+    if (by_pair && n >= (1ull << 32)) return fail(TA_EINVAL, "too many records (%llu) for the grouped fetch", (unsigned long long)n);
+    DevBuf buf;
+    uint32_t* gpa = nullptr; int32_t* gco = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess && (rc = wall_records_device(c, by_pair, buf, &gpa, &gco, e0, e1)) != TA_OK) {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        buf.release();
+        return rc;
+    }
     if (e == hipSuccess) e = hipMemcpyAsync(pairs, gpa, n * 8, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(coords, gco, n * 12, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -795,6 +819,82 @@ int wall_voxels_fetch(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_ou
     return TA_OK;
 }
 }  // namespace
+
+TA_API int ta_wall_medians(ta_ctx* c, int max_iter, int64_t* nwalls, double* ms_out) {
+    if (!c || !nwalls) return fail(TA_EINVAL, "NULL argument");
+    if (c->wall_records < 0) return fail(TA_EINVAL, "call ta_wall_voxels_count first");
+    if (max_iter < 1) return fail(TA_EINVAL, "max_iter must be positive");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t n = (uint64_t)c->wall_records;
+    c->wall_median_count = -1;
+    *nwalls = 0;
+    if (ms_out) *ms_out = 0.0;
+    if (n == 0) { c->wall_median_count = 0; return TA_OK; }
+    if (n >= (1ull << 32)) return fail(TA_EINVAL, "too many records (%llu) for the grouped fetch", (unsigned long long)n);
+    DevBuf buf, scratch, starts;
+    uint32_t* gpa = nullptr; int32_t* gco = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipError_t e = hipEventCreate(&e0);
+    if (e == hipSuccess) e = hipEventCreate(&e1);
+    if (e == hipSuccess) e = hipEventRecord(e0, c->stream);
+    rc = e == hipSuccess ? wall_records_device(c, true, buf, &gpa, &gco, nullptr, nullptr) : TA_EHIP;
+    if (rc == TA_OK) rc = scratch.reserve(ta::wall_median_scratch_bytes(n));
+    if (rc == TA_OK) rc = starts.reserve(n * 4 + 16);
+    uint64_t E = 0;
+    uint32_t status = 0;
+    if (rc == TA_OK) {
+        uint64_t* total_dev = nullptr;
+        ta::launch_wall_starts(c->stream, gpa, n, scratch.p, (uint32_t*)starts.p, &total_dev);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&E, total_dev, sizeof(E), hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) rc = c->wall_medians.reserve(E * 24 + 16);
+        if (e == hipSuccess && rc == TA_OK) {
+            uint32_t* op = (uint32_t*)c->wall_medians.p;
+            uint32_t* os = op + 2 * E;
+            int32_t* om = (int32_t*)(os + E);
+            uint32_t* st = (uint32_t*)scratch.p;                          // (the flags are dead: their first word takes the status)
+            e = hipMemsetAsync(st, 0, 4, c->stream);
+            if (e == hipSuccess) {
+                ta::launch_wall_medians(c->stream, gpa, gco, (const uint32_t*)starts.p, (uint32_t)E, n, max_iter, op, os, om, st);
+                e = hipGetLastError();
+            }
+            if (e == hipSuccess) e = hipEventRecord(e1, c->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(&status, st, 4, hipMemcpyDeviceToHost, c->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        }
+    }
+    float ms = 0.f;
+    if (rc == TA_OK && e == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    if (e0) (void)hipEventDestroy(e0);
+    if (e1) (void)hipEventDestroy(e1);
+    buf.release(); scratch.release(); starts.release();
+    if (rc != TA_OK) return rc;
+    if (e != hipSuccess) return fail(TA_EHIP, "wall medians: %s", hipGetErrorString(e));
+    if (status) return fail(TA_EINVAL, "Weiszfeld iteration: a wall is still moving after %d passes", max_iter);
+    c->wall_median_count = (int64_t)E;
+    *nwalls = (int64_t)E;
+    if (ms_out) *ms_out = ms;
+    return TA_OK;
+}
+
+TA_API int ta_wall_medians_get(ta_ctx* c, uint32_t* pairs, uint32_t* sizes, int32_t* medians) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if (c->wall_median_count < 0) return fail(TA_EINVAL, "call ta_wall_medians first");
+    const uint64_t E = (uint64_t)c->wall_median_count;
+    if (E == 0) return TA_OK;
+    if (!pairs || !sizes || !medians) return fail(TA_EINVAL, "NULL output array");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint32_t* op = (const uint32_t*)c->wall_medians.p;
+    TA_HIP(hipMemcpyAsync(pairs, op, E * 8, hipMemcpyDeviceToHost, c->stream));
+    TA_HIP(hipMemcpyAsync(sizes, op + 2 * E, E * 4, hipMemcpyDeviceToHost, c->stream));
+    TA_HIP(hipMemcpyAsync(medians, op + 3 * E, E * 12, hipMemcpyDeviceToHost, c->stream));
+    TA_HIP(hipStreamSynchronize(c->stream));
+    return TA_OK;
+}
+
 
 TA_API int ta_wall_voxels_get(ta_ctx* c, uint32_t* pairs, int32_t* coords, double* ms_out) {
     return wall_voxels_fetch(c, pairs, coords, ms_out, false);

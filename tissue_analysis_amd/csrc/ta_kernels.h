@@ -71,6 +71,13 @@ hipError_t launch_wall_group_by_pair(hipStream_t s, const uint32_t* pairs, const
 // kernels_walls.hip (continued): exclusive scan of uint32 counts into uint64 offsets (three small kernels)
 uint64_t scan_u32_scratch_bytes(uint64_t n);
 void launch_scan_u32_exclusive(hipStream_t s, const uint32_t* counts, uint64_t n, void* scratch, uint64_t* offsets);
+uint64_t* scan_u32_total(void* scratch, uint64_t n);        // where that scan leaves the sum of all counts (device)
+
+// kernels_wallmedian.hip -- the median voxel of every wall, from the records grouped by pair (one thread per wall)
+uint64_t wall_median_scratch_bytes(uint64_t n);
+void launch_wall_starts(hipStream_t s, const uint32_t* pairs, uint64_t n, void* scratch, uint32_t* starts, uint64_t** nwalls_dev);
+void launch_wall_medians(hipStream_t s, const uint32_t* pairs, const int32_t* coords, const uint32_t* starts, uint32_t nwalls, uint64_t n,
+                         int max_iter, uint32_t* out_pairs, uint32_t* out_sizes, int32_t* out_medians, uint32_t* status);
 
 // kernels_pairsort.hip -- the unique pairs sorted by (lo, hi): counting sort over the label rows + rank inside a bucket
 uint64_t pairs_sort_scratch_bytes(uint64_t n, uint32_t max_label);

@@ -378,6 +378,16 @@ class ResidentVolume(object):
             lo, hi, coords = lo[order], hi[order], coords[order]
         return WallTable(lo, hi, coords, ms)
 
+    def wall_medians(self, max_iter=200):
+        """(keys uint64[E] ascending = lo << 32 | hi, sizes[E], medians int64[E, 3]) of every wall, computed on the device
+        from the records grouped by pair -- or None when the image is not C-ordered (the order of a wall's voxels decides
+        ties: the caller then works from wall_table() on the host)."""
+        if not self.host.flags.c_contiguous:
+            return None
+        keys, sizes, med, ms = self.ctx.wall_medians(max_iter)
+        self.ms["wall_medians"] = ms
+        return keys, sizes, med.astype(np.int64)
+
     def relabel(self, lut, features=_capi.F_ALL):
         """v -> lut[v] on the resident volume AND on `self.host` (copied back), then sweep the new volume."""
         self.ctx.relabel(lut)

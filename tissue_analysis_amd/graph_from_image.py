@@ -12,8 +12,9 @@ numbers.  How it computes them is unrelated to the reference's dict-and-loop cod
     columns   volume / barycenter / boundingbox / inertia: row gathers of the accumulators;
               L1, epidermis_surface: the pairs holding the background; border: a test on the bounding boxes;
               wall_surface: faces . face areas of the edge rows; unlabelled_wall_surface: a bincount over the pairs with
-              exactly one requested end; wall medians: segment reductions over the wall-voxel records the device grouped
-              by pair (geometry.median_voxels).
+              exactly one requested end; wall medians: computed ON THE DEVICE from the wall-voxel records it grouped by pair
+              (ta_wall_medians: E x 3 integers come back), or by the same arithmetic on the host (geometry.median_voxels)
+              when a wall table is on the host already.
 
 Rules of the reference that are kept because they decide results (each pinned by tests against oracle/graph_oracle.py):
   * `availables_spatial_properties()` advertises 'wall_area' / 'epidermis_area' but the builder tests for 'wall_surface' /
@@ -32,7 +33,6 @@ from __future__ import annotations
 
 import numpy as np
 
-from .geometry import gather_segments, median_voxels
 from .property_graph import PropertyGraph
 from .spatial_image_analysis import AbstractSpatialImageAnalysis, DICT, SpatialImageAnalysis
 
@@ -105,14 +105,9 @@ def _wall_median_columns(graph, analysis, pairs, background):
     bg = -1 if background is None else int(background)
     want = pairs.kept & ((pairs.lo_in & pairs.hi_in) | (pairs.lo_in & (pairs.hi == bg)) | (pairs.hi_in & (pairs.lo == bg)))
     lo, hi = pairs.lo[want], pairs.hi[want]
-    table = analysis.wall_table()
     key = (lo.astype(np.uint64) << np.uint64(32)) | hi.astype(np.uint64)
-    at = np.searchsorted(table.pairs, key)
-    found = at < table.pairs.size
-    found[found] = table.pairs[at[found]] == key[found]
-    lo, hi, at = lo[found], hi[found], at[found]
-    rows, sizes = gather_segments(table.start[at], table.stop[at])
-    chosen = median_voxels(table.coords[rows].astype(np.int64), sizes).reshape(-1, 3)
+    found, chosen = analysis.wall_medians_of(key)          # (on the device when the analysis holds a resident volume)
+    lo, hi = lo[found], hi[found]
 
     V, E = graph.nb_vertices(), graph.nb_edges()
     edge_value, edge_valid = np.zeros((E, 3), dtype=np.int64), np.zeros(E, dtype=bool)
