@@ -250,7 +250,7 @@ TA_API int ta_wall_voxels_get_by_pair(ta_ctx* ctx, uint32_t* pairs /* [n][2] */,
 /* The median voxel of every wall, computed on the device (TGI:210-242 through SIA:1586-1635; new in TA_ABI_VERSION 3, the
  * reference has no native interface to mirror): after ta_wall_voxels_count, ta_wall_medians groups the records by pair on
  * the device, runs the reference's Weiszfeld iteration (its start, its stopping rule, IEEE double sums in record order: the
- * arithmetic of tissue_analysis_amd/geometry.py::weiszfeld_segments) on every wall -- one thread a wall --, truncates the
+ * arithmetic of tissue_analysis_amd/geometry.py::weiszfeld_segments) on every wall -- one wave a wall --, truncates the
  * position and picks the wall voxel nearest to it (the first one on ties).  *nwalls = number of walls E; the results stay
  * on the context until the volume changes.  ta_wall_medians_get copies them out, sorted by (lo, hi): pairs u32[E][2], the
  * walls' voxel counts u32[E], the median voxels i32[E][3] in array-axis order.  TA_EINVAL when a wall is still moving after

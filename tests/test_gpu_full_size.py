@@ -132,7 +132,7 @@ def test_c2_wall_medians_end_to_end_on_the_device(capsys):
     t_host = time.perf_counter() - t0
     with capsys.disabled():
         print("\n[C2 wall medians: %d walls, %d wall-voxel records] graph_from_image(..., 'wall_median') end to end %.1f ms with the medians "
-              "on the device (group by pair + one thread a wall: %.2f ms of kernels); the route of rounds 2-3: %.1f ms to fetch the grouped "
+              "on the device (group by pair + one wave a wall: %.2f ms of kernels); the route of rounds 2-3: %.1f ms to fetch the grouped "
               "records + %.1f ms of host arithmetic" % (keys.size, int(sizes.sum()), t_dev * 1e3, kernels_ms, t_fetch * 1e3, t_host * 1e3))
     assert len(g.edge_property('wall_median')) > 10000
 

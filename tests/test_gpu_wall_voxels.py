@@ -154,7 +154,7 @@ def _flat_symmetric_walls():
                                   _flat_symmetric_walls, lambda: random_blocks((14, 18, 30), 60, 73, np.uint32)],
                          ids=["voronoi_u16", "voronoi_u32", "flat_symmetric", "blocks_u32"])
 def test_wall_medians_on_the_device_equal_the_host_arithmetic(gpu_ctx, make):
-    """ta_wall_medians (one thread a wall: the reference's Weiszfeld rules in IEEE double, sums in record order, truncation,
+    """ta_wall_medians (one wave a wall: the reference's Weiszfeld rules in IEEE double, sums in record order, truncation,
     nearest wall voxel) against geometry.median_voxels on the records the device grouped by pair: the same voxel for EVERY wall."""
     from tissue_analysis_amd import geometry
     vol = make()

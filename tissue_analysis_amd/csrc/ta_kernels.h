@@ -73,7 +73,7 @@ uint64_t scan_u32_scratch_bytes(uint64_t n);
 void launch_scan_u32_exclusive(hipStream_t s, const uint32_t* counts, uint64_t n, void* scratch, uint64_t* offsets);
 uint64_t* scan_u32_total(void* scratch, uint64_t n);        // where that scan leaves the sum of all counts (device)
 
-// kernels_wallmedian.hip -- the median voxel of every wall, from the records grouped by pair (one thread per wall)
+// kernels_wallmedian.hip -- the median voxel of every wall, from the records grouped by pair (one wave per wall)
 uint64_t wall_median_scratch_bytes(uint64_t n);
 void launch_wall_starts(hipStream_t s, const uint32_t* pairs, uint64_t n, void* scratch, uint32_t* starts, uint64_t** nwalls_dev);
 void launch_wall_medians(hipStream_t s, const uint32_t* pairs, const int32_t* coords, const uint32_t* starts, uint32_t nwalls, uint64_t n,
