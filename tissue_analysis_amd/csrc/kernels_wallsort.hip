@@ -1,21 +1,99 @@
-// kernels_wallsort.hip -- the wall-voxel records grouped by label pair ON THE DEVICE (what every caller of the table
-// wants: WallTable used to do a stable host sort of ~10^7 records).  A stable LSD radix sort (hipCUB / rocPRIM, a plain
-// library sort) of key = lo << bits | hi -- bits = what a label of this volume takes, found by the count pass -- with the
-// record index as value keeps the memory order inside each pair; a gather then writes the records in that order.  Kept in its own file: the library headers are slow to compile.
+// kernels_wallsort.hip -- the wall-voxel records grouped by label pair ON THE DEVICE (what every caller of the table wants).
+//
+// A STABLE least-significant-digit radix sort, hand-written (rounds 2-3 called hipCUB's): key = lo << bits | hi -- bits = what a
+// label of this volume takes, found by the count pass, so the sort runs over 2 x bits instead of 64 -- with the record index
+// as value; stable, so each pair's voxels stay in memory order; a gather then writes the records in that order.
+// One pass per 8-bit digit, three kernels a pass:
+//   histogram  a workgroup counts the digits of its tile of 4096 keys in LDS and writes hist[digit][workgroup];
+//   scan       an exclusive scan over that table (digit-major) = where each workgroup's keys of each digit start;
+//   scatter    a wave owns 1024 consecutive keys of the tile and walks them 64 at a time, IN ORDER: a lane's rank among the
+//              lanes of its chunk that hold the same digit comes from eight ballots (one per digit bit), its position from
+//              the wave's running cursor of that digit in LDS -- no key ever overtakes an equal one.
+// HBM-bound in principle (two reads + one write of 8 bytes a record per pass); the scatter's writes are runs of equal pairs.
 #include "ta_kernels.h"
-
-#include <hipcub/hipcub.hpp>
 
 namespace ta {
 
-// key = lo << bits | hi with `bits` = the bits a label of this volume takes: the sort runs over 2 x bits instead of 48 / 64,
-// and over 32-bit keys where that fits (labels below 2^16: every uint16 volume, most uint32 ones)
+constexpr int RS_WAVES = 4, RS_PER_WAVE = 1024, RS_TILE = RS_WAVES * RS_PER_WAVE;      // keys per workgroup
+
 template <typename K>
 __global__ void __launch_bounds__(256) wall_sort_keys_kernel(const uint2* pairs, uint64_t n, K* keys, uint32_t* index, int bits) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint2 p = pairs[i];
         keys[i] = (K)(((uint64_t)p.x << bits) | p.y);
         index[i] = (uint32_t)i;
+    }
+}
+
+// The lanes of a chunk that hold the same digit as this lane (eight ballots, one per digit bit).
+__device__ __forceinline__ uint64_t digit_peers(const uint32_t d, const bool valid) {
+    uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+        const bool bit = (d >> b) & 1u;
+        const uint64_t m = __builtin_amdgcn_ballot_w64(valid && bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+// (Counting the digits with one fire-and-forget LDS atomic per key puts many lanes on one address -- a wall's records are
+//  neighbours in memory -- which the CU serialises; counting by one lane per group of equal digits, through digit_peers, was
+//  built and is SLOWER -- C2 1.98 against 1.44 ms for the grouped fetch: three rounds of eight ballots a chunk and a
+//  read-modify-write the wave has to wait for cost more than the serialised atomics nobody waits for.)
+template <typename K>
+__global__ void __launch_bounds__(256) radix_hist_kernel(const K* keys, uint64_t n, int shift, uint32_t* hist, uint32_t nblocks) {
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
+#pragma unroll 4
+    for (int k = 0; k < RS_TILE / 256; ++k) {
+        const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+}
+
+template <typename K>
+__global__ void __launch_bounds__(256) radix_scatter_kernel(const K* keys_in, const uint32_t* vals_in, uint64_t n, int shift,
+                                                            const uint64_t* offs, uint32_t nblocks, K* keys_out, uint32_t* vals_out) {
+    __shared__ uint32_t cursor[RS_WAVES][256];          // first the digit counts of each wave, then its running cursors
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int k = 0; k < RS_WAVES; ++k) cursor[k][tid] = 0u;
+    __syncthreads();
+    const uint64_t wbase = (uint64_t)blockIdx.x * RS_TILE + (uint64_t)w * RS_PER_WAVE;
+    const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;                  // the lanes before this one
+    K key[RS_PER_WAVE / 64];
+    uint32_t val[RS_PER_WAVE / 64];
+#pragma unroll
+    for (int c = 0; c < RS_PER_WAVE / 64; ++c) {
+        const uint64_t i = wbase + (uint64_t)c * 64 + lane;
+        key[c] = i < n ? keys_in[i] : (K)0;
+        val[c] = i < n ? vals_in[i] : 0u;
+        if (i < n) atomicAdd(&cursor[w][(uint32_t)(key[c] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    {   // thread t owns digit t: where the workgroup's keys of that digit start, then wave by wave
+        uint32_t at = (uint32_t)offs[(uint64_t)tid * nblocks + blockIdx.x];
+#pragma unroll
+        for (int k = 0; k < RS_WAVES; ++k) { const uint32_t cnt = cursor[k][tid]; cursor[k][tid] = at; at += cnt; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < RS_PER_WAVE / 64; ++c) {
+        const bool valid = wbase + (uint64_t)c * 64 + lane < n;
+        const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
+        const uint64_t peers = digit_peers(d, valid);
+        const uint32_t rank = (uint32_t)__builtin_popcountll(peers & lt);
+        uint32_t pos = 0u;
+        if (valid) pos = cursor[w][d] + rank;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (valid && rank == 0u) cursor[w][d] += (uint32_t)__builtin_popcountll(peers);      // one lane per digit of the chunk
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (valid) { keys_out[pos] = key[c]; vals_out[pos] = val[c]; }
     }
 }
 
@@ -32,29 +110,35 @@ __global__ void __launch_bounds__(256) wall_gather_kernel(const K* keys, const u
     }
 }
 
+static uint64_t rs_blocks(uint64_t n) { return (n + RS_TILE - 1) / RS_TILE; }
+
+// hist u32[256][blocks] | offsets u64[256][blocks] | scan scratch
 uint64_t wall_sort_temp_bytes(uint64_t n) {
-    size_t wide = 0, narrow = 0;
-    hipcub::DoubleBuffer<uint64_t> dk(nullptr, nullptr);
-    hipcub::DoubleBuffer<uint32_t> dn(nullptr, nullptr);
-    hipcub::DoubleBuffer<uint32_t> dv(nullptr, nullptr);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, wide, dk, dv, (int64_t)n, 0, 64, nullptr);
-    (void)hipcub::DeviceRadixSort::SortPairs(nullptr, narrow, dn, dv, (int64_t)n, 0, 32, nullptr);
-    return (uint64_t)(wide > narrow ? wide : narrow);
+    const uint64_t cells = 256 * rs_blocks(n);
+    return ((cells * 4 + 15) & ~15ull) + ((cells * 8 + 15) & ~15ull) + scan_u32_scratch_bytes(cells) + 64;
 }
 
 template <typename K>
 static hipError_t wall_group(hipStream_t s, const uint32_t* pairs, const int32_t* coords, uint64_t n, K* keys0, K* keys1,
-                             uint32_t* index0, uint32_t* index1, void* temp, uint64_t temp_bytes, int bits, uint32_t* pairs_out,
-                             int32_t* coords_out) {
+                             uint32_t* index0, uint32_t* index1, void* temp, int bits, uint32_t* pairs_out, int32_t* coords_out) {
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(wall_sort_keys_kernel<K>, dim3(blocks), dim3(256), 0, s, (const uint2*)pairs, n, keys0, index0, bits);
-    hipcub::DoubleBuffer<K> dk(keys0, keys1);
-    hipcub::DoubleBuffer<uint32_t> dv(index0, index1);
-    size_t bytes = (size_t)temp_bytes;
-    hipError_t e = hipcub::DeviceRadixSort::SortPairs(temp, bytes, dk, dv, (int64_t)n, 0, 2 * bits, s);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(wall_gather_kernel<K>, dim3(blocks), dim3(256), 0, s, dk.Current(), dv.Current(), (const WallInt3*)coords, n,
+    const uint32_t nb = (uint32_t)rs_blocks(n);
+    const uint64_t cells = 256ull * nb;
+    char* p = (char*)temp;
+    uint32_t* hist = (uint32_t*)p; p += (cells * 4 + 15) & ~15ull;
+    uint64_t* offs = (uint64_t*)p; p += (cells * 8 + 15) & ~15ull;
+    K* kin = keys0; K* kout = keys1;
+    uint32_t* vin = index0; uint32_t* vout = index1;
+    for (int shift = 0; shift < 2 * bits; shift += 8) {
+        hipLaunchKernelGGL(radix_hist_kernel<K>, dim3(nb), dim3(256), 0, s, kin, n, shift, hist, nb);
+        launch_scan_u32_exclusive(s, hist, cells, p, offs);
+        hipLaunchKernelGGL(radix_scatter_kernel<K>, dim3(nb), dim3(256), 0, s, kin, vin, n, shift, offs, nb, kout, vout);
+        K* tk = kin; kin = kout; kout = tk;
+        uint32_t* tv = vin; vin = vout; vout = tv;
+    }
+    hipLaunchKernelGGL(wall_gather_kernel<K>, dim3(blocks), dim3(256), 0, s, kin, vin, (const WallInt3*)coords, n,
                        (uint2*)pairs_out, (WallInt3*)coords_out, bits);
     return hipGetLastError();
 }
@@ -65,13 +149,14 @@ static hipError_t wall_group(hipStream_t s, const uint32_t* pairs, const int32_t
 hipError_t launch_wall_group_by_pair(hipStream_t s, const uint32_t* pairs, const int32_t* coords, uint64_t n, uint64_t* keys0,
                                      uint64_t* keys1, uint32_t* index0, uint32_t* index1, void* temp, uint64_t temp_bytes,
                                      int label_bits, uint32_t* pairs_out, int32_t* coords_out) {
+    (void)temp_bytes;
     if (n == 0) return hipSuccess;
     if (label_bits < 1) label_bits = 1;
     if (label_bits > 32) label_bits = 32;
     if (2 * label_bits <= 32)
-        return wall_group<uint32_t>(s, pairs, coords, n, (uint32_t*)keys0, (uint32_t*)keys1, index0, index1, temp, temp_bytes, label_bits,
+        return wall_group<uint32_t>(s, pairs, coords, n, (uint32_t*)keys0, (uint32_t*)keys1, index0, index1, temp, label_bits,
                                     pairs_out, coords_out);
-    return wall_group<uint64_t>(s, pairs, coords, n, keys0, keys1, index0, index1, temp, temp_bytes, label_bits, pairs_out, coords_out);
+    return wall_group<uint64_t>(s, pairs, coords, n, keys0, keys1, index0, index1, temp, label_bits, pairs_out, coords_out);
 }
 
 }  // namespace ta
