@@ -33,8 +33,10 @@ extern "C" {
 
 /* 2: ta_wall_voxels_get takes (pairs, coords, ms); ta_ctx_set_stream(NULL) = the device's legacy default stream;
  *    TA_OPT_IMPL is 0 or 1; ta_adjacency_scope added; ta_timing answers zeros when no events were recorded.
+ * 3: ta_volume_plane_events, ta_wall_medians(_get); ta_timing answers NaN for what was not measured.
+ * 4: sparse label ids: ta_volume_label_census, ta_label_census_get, ta_volume_compact_labels, ta_volume_is_compact.
  * A caller checks ta_version() == TA_ABI_VERSION of the header it was built against (the ctypes binding does). */
-#define TA_ABI_VERSION 3
+#define TA_ABI_VERSION 4
 
 #if defined(TA_BUILD)
 #define TA_API __attribute__((visibility("default")))
@@ -111,6 +113,23 @@ TA_API int ta_volume_set_device(ta_ctx* ctx, const void* dev_ptr, int itemsize,
 
 /* Largest label in the resident volume (device max-reduction; ~ np.unique(image) SIA:363). */
 TA_API int ta_volume_max_label(ta_ctx* ctx, uint32_t* max_label);
+
+/* ---- sparse label ids (np.unique takes any ids, SIA:358-364; the sweep keeps one 104-byte row per id 0..max_label) --------
+ * ta_volume_label_census: which ids does the resident volume (halo plane included) hold -- np.unique on the device: one
+ *   presence-bitmap pass over the volume, a prefix count over (max_label + 1) / 32 words.  ta_label_census_get: the ids, ascending.
+ * ta_volume_compact_labels: from then on the SWEEP reads a context-owned copy of the volume rewritten in the RANKS of its ids
+ *   (0 .. n_rows - 1, order-preserving); the resident volume itself is not touched, so the wall voxels, the label maps and the
+ *   voxel layers keep working on ids.  In a compacted context every per-label ROW (ta_get_labels, ta_accumulators_device,
+ *   ta_bind_accumulators: pass max_label = n_rows - 1 to ta_extract) is indexed by rank, and every label VALUE a getter hands
+ *   out (ta_adjacency_get) is an id; ta_label_census_get is the rank -> id table.  ids == NULL: the census of this volume;
+ *   otherwise a HOST list, ascending and unique, that must cover the volume (TA_ERANGE if it does not): the union over the ranks
+ *   of a partitioned volume, so that every slab ranks alike and the device-side adjacency exchange works in rank space.
+ *   More than 2^28 - 1 ids present => TA_ERANGE.  A new volume or ta_volume_relabel ends the compacted state.
+ * New in TA_ABI_VERSION 4. */
+TA_API int ta_volume_label_census(ta_ctx* ctx, uint32_t* max_label, uint32_t* n_present);
+TA_API int ta_label_census_get(ta_ctx* ctx, uint32_t* ids /* [n_present] */);
+TA_API int ta_volume_compact_labels(ta_ctx* ctx, const uint32_t* ids, uint32_t n_ids, uint32_t* n_rows);
+TA_API int ta_volume_is_compact(ta_ctx* ctx, int* compact, uint32_t* n_rows);
 
 /* events[p] = label changes along memory axis 2 in OWNED plane p of the resident volume (one streaming pass; the halo
  * plane of a slab is not counted): what a record-producing plane costs the sweep on top of its voxels -- the weight a

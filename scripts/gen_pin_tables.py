@@ -15,7 +15,8 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 OUT = os.path.join(ROOT, "tissue_analysis_amd", "csrc", "ta_pin_tables.inc")
 TABLES = [(104, True), (120, True), (76, False), (80, False)]      # (first pinned register, with adjacency)
-TWO_ROW_TABLES = [82, 112]      # adjacency, TWO rows per wave only: 13 registers (rows, row above, voxel to the left); 112: the padded tiles
+TWO_ROW_TABLES = [82, 112, 96]  # adjacency, TWO rows per wave only: 13 registers (rows, row above, voxel to the left); 112: the padded tiles;
+                                # 95: the second landing zone of the two-planes-in-flight experiment (behind 82's)
 
 
 def clobbers(base, n):
@@ -87,6 +88,14 @@ def table_two_rows(base):
     o.append("    template <int RB> static __device__ __forceinline__ void landed(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {")
     o.append('        static_assert(RB == 2, "this budget holds two rows");')
     o.append('        asm volatile("s_waitcnt vmcnt(0)\\n" %s' % movs(base, 13))
+    o.append('                     : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),')
+    o.append('                       "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)')
+    o.append('                     :: "memory");')
+    o.append("    }")
+    o.append("    // (the same with the FOUR youngest loads -- the next plane's, in the other landing zone -- left in flight)")
+    o.append("    template <int RB> static __device__ __forceinline__ void landed_keep4(u32x4 (&raw)[RB], u32x4& upr, uint32_t& l) {")
+    o.append('        static_assert(RB == 2, "this budget holds two rows");')
+    o.append('        asm volatile("s_waitcnt vmcnt(4)\\n" %s' % movs(base, 13))
     o.append('                     : "=&v"(raw[0].x), "=&v"(raw[0].y), "=&v"(raw[0].z), "=&v"(raw[0].w),')
     o.append('                       "=&v"(raw[1].x), "=&v"(raw[1].y), "=&v"(raw[1].z), "=&v"(raw[1].w), "=&v"(upr.x), "=&v"(upr.y), "=&v"(upr.z), "=&v"(upr.w), "=&v"(l)')
     o.append('                     :: "memory");')

@@ -17,7 +17,7 @@ TA_OK, TA_EINVAL, TA_EHIP, TA_ENOMEM, TA_ERANGE, TA_ECAPACITY, TA_ENODEVICE = 0,
 F_VOLUME, F_BBOX, F_MOMENT1, F_MOMENT2, F_ADJACENCY = 1, 2, 4, 8, 16
 F_ALL = 31
 ADJ_LOCAL, ADJ_MERGED, ADJ_PARTIAL = 0, 1, 2
-ABI_VERSION = 3          # TA_ABI_VERSION of include/tissue_scan.h this binding was written against
+ABI_VERSION = 4          # TA_ABI_VERSION of include/tissue_scan.h this binding was written against
 FEATURES = dict(VOLUME=F_VOLUME, BBOX=F_BBOX, MOMENT1=F_MOMENT1, MOMENT2=F_MOMENT2,
                 ADJACENCY=F_ADJACENCY)
 OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS, OPT_TIMING, OPT_TIMING_RING, OPT_VOLUME_SLACK = 1, 2, 3, 4, 5, 6
@@ -27,7 +27,8 @@ STREAM_LEGACY_DEFAULT = 1          # TA_STREAM_LEGACY_DEFAULT of include/tissue_
 SYMBOLS = (
     "ta_version", "ta_adjacency_scope", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_get_option", "ta_ctx_synchronize", "ta_volume_set",
-    "ta_volume_set_device", "ta_volume_max_label", "ta_volume_plane_events", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
+    "ta_volume_set_device", "ta_volume_max_label", "ta_volume_label_census", "ta_label_census_get", "ta_volume_compact_labels",
+    "ta_volume_is_compact", "ta_volume_plane_events", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
     "ta_volume_first_layer", "ta_volume_hollow", "ta_volume_layer18", "ta_wall_voxels_count", "ta_wall_voxels_get", "ta_wall_voxels_get_by_pair",
     "ta_wall_medians", "ta_wall_medians_get",
     "ta_extract", "ta_get_labels",
@@ -87,6 +88,10 @@ def load():
         "ta_volume_set": (ci, [vp, vp, ci, P(i64), P(i64)]),
         "ta_volume_set_device": (ci, [vp, vp, ci, P(i64), i64, ci]),
         "ta_volume_max_label": (ci, [vp, P(u32)]),
+        "ta_volume_label_census": (ci, [vp, P(u32), P(u32)]),
+        "ta_label_census_get": (ci, [vp, vp]),
+        "ta_volume_compact_labels": (ci, [vp, vp, u32, P(u32)]),
+        "ta_volume_is_compact": (ci, [vp, P(ci), P(u32)]),
         "ta_volume_plane_events": (ci, [vp, vp]),
         "ta_volume_relabel": (ci, [vp, vp, u32]),
         "ta_volume_get": (ci, [vp, vp]),
@@ -345,6 +350,47 @@ class Context(object):
         v = ctypes.c_uint32(0)
         _check(self._lib.ta_volume_max_label(self._h, ctypes.byref(v)))
         return v.value
+
+    # -- sparse label ids
+    def label_census(self):
+        """(max id, ascending uint32 ids present in the resident volume): np.unique on the device."""
+        top, n = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        _check(self._lib.ta_volume_label_census(self._h, ctypes.byref(top), ctypes.byref(n)))
+        ids = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            _check(self._lib.ta_label_census_get(self._h, ids.ctypes.data_as(ctypes.c_void_p)))
+        return top.value, ids
+
+    def compact_labels(self, ids=None):
+        """From now on the sweep reads a copy of the volume written in the RANKS of its ids (`ids`: an ascending unique list
+        that covers the volume, e.g. the union over the slabs of a partitioned volume; None = this volume's own census).
+        Returns the rank -> id table (uint32): rows of `labels()` are ranks, `adjacency()` answers in ids."""
+        n = ctypes.c_uint32(0)
+        if ids is None:
+            _check(self._lib.ta_volume_compact_labels(self._h, None, 0, ctypes.byref(n)))
+        else:
+            ids = np.ascontiguousarray(ids, dtype=np.uint32)
+            _check(self._lib.ta_volume_compact_labels(self._h, ids.ctypes.data_as(ctypes.c_void_p), ids.size, ctypes.byref(n)))
+        out = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            _check(self._lib.ta_label_census_get(self._h, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
+
+    def is_compact(self):
+        flag, n = ctypes.c_int(0), ctypes.c_uint32(0)
+        _check(self._lib.ta_volume_is_compact(self._h, ctypes.byref(flag), ctypes.byref(n)))
+        return bool(flag.value)
+
+    def compact_ids(self):
+        """The rank -> id table of a compacted context (uint32, ascending)."""
+        flag, n = ctypes.c_int(0), ctypes.c_uint32(0)
+        _check(self._lib.ta_volume_is_compact(self._h, ctypes.byref(flag), ctypes.byref(n)))
+        if not flag.value:
+            raise TissueScanError(TA_EINVAL, "the context is not compacted")
+        out = np.zeros(n.value, dtype=np.uint32)
+        if n.value:
+            _check(self._lib.ta_label_census_get(self._h, out.ctypes.data_as(ctypes.c_void_p)))
+        return out
 
     # -- hot path
     def plane_events(self):

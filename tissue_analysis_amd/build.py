@@ -14,7 +14,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJDIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libtissue_scan.so")
-SOURCES = ["ta_api.hip", "kernels_basic.hip", "kernels_scan.hip", "kernels_walls.hip", "kernels_wallsort.hip", "kernels_wallmedian.hip",
+SOURCES = ["ta_api.hip", "kernels_basic.hip", "kernels_scan.hip", "kernels_walls.hip", "kernels_wallsort.hip", "kernels_wallmedian.hip", "kernels_census.hip",
            "kernels_pairsort.hip"]
 HEADERS = ["ta_device.h", "ta_kernels.h", "ta_sweep_common.h", "ta_pin_tables.inc", os.path.join("..", "..", "include", "tissue_scan.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
@@ -81,7 +81,7 @@ def _check_pinned(hipcc, verbose=False):
             elif "scan_noadj_kernel" in func:
                 ranges = [bases["MOM"]]
             elif "scan_two_rows_kernel" in func:
-                ranges = [bases["ADJ2"]]
+                ranges = [bases["ADJ2"], bases["ADJ2"] + 6]    # (+6: the second landing zone of TA_PLANES_IN_FLIGHT=2, v[96:108])
             elif "scan_kernel" in func:
                 ranges = [bases["ADJ"]]
             else:

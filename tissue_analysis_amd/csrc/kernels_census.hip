@@ -1,0 +1,210 @@
+// kernels_census.hip -- which label ids does the volume hold, and the volume rewritten in their RANKS (sparse label ids).
+//
+// The reference takes any ids (np.unique(image), SIA:358-364); the sweep keeps one 104-byte row per id 0..max_label, which a
+// volume with a few thousand cells numbered near 2^31 cannot afford.  The census is the device form of np.unique:
+//   census[w] = { bits, below }   bits  = bit b set <=> id 32 w + b occurs in the volume (one atomicOr per FIRST sighting:
+//                                        the word is read first, and a thread skips a voxel equal to the one before it)
+//                                 below = number of ids present in words 0 .. w-1 (three-kernel exclusive scan of popcounts)
+// so rank(v) = census[v >> 5].below + popc(census[v >> 5].bits & ((1 << (v & 31)) - 1)) is ONE 8-byte gather per voxel, the
+// ranks are dense 0 .. n-1 and ORDER-PRESERVING (everything the sweep orders by label -- lo < hi, the sorted pair list --
+// carries over), and ids[rank] (expanded from the same words) maps the rows back.  All of it is HBM-bound streaming over the
+// volume plus a table of (max_label + 1) / 4 bytes.
+#include "ta_kernels.h"
+
+namespace ta {
+
+namespace {
+
+constexpr int CENSUS_WORDS_PER_BLOCK = 4096;     // 256 threads x 16 words
+
+__device__ __forceinline__ void census_mark(uint2* census, uint32_t v) {
+    uint32_t* w = &census[v >> 5].x;
+    const uint32_t bit = 1u << (v & 31u);
+    if (!(__builtin_nontemporal_load(w) & bit)) atomicOr(w, bit);      // (a stale read only costs a redundant atomic)
+}
+
+template <typename T>
+__global__ void __launch_bounds__(256) census_mark_kernel(const T* __restrict__ vol, uint64_t n, uint64_t nvec, uint2* census) {
+    constexpr int PER = 16 / (int)sizeof(T);
+    const uint4* v4 = reinterpret_cast<const uint4*>(vol);
+    uint32_t prev = 0xffffffffu;
+    bool have = false;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 x = v4[i];
+        const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (sizeof(T) == 4) {
+                if (!have || w[k] != prev) { census_mark(census, w[k]); prev = w[k]; have = true; }
+            } else {
+                const uint32_t a = w[k] & 0xffffu, b = w[k] >> 16;
+                if (!have || a != prev) { census_mark(census, a); prev = a; have = true; }
+                if (b != prev) { census_mark(census, b); prev = b; }
+            }
+        }
+    }
+    for (uint64_t t = nvec * PER + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x)
+        census_mark(census, (uint32_t)vol[t]);
+}
+
+// a census from a LIST of ids (the union over the ranks of a partitioned volume: every rank then ranks alike)
+__global__ void __launch_bounds__(256) census_from_ids_kernel(const uint32_t* __restrict__ ids, uint64_t n, uint2* census) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicOr(&census[ids[i] >> 5].x, 1u << (ids[i] & 31u));
+}
+
+__device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* lds) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    if ((threadIdx.x & 63) == 0) lds[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return lds[0] + lds[1] + lds[2] + lds[3];
+}
+
+__global__ void __launch_bounds__(256) census_block_sums_kernel(const uint2* __restrict__ census, uint64_t words, uint32_t* block_sums) {
+    __shared__ uint32_t lds[4];
+    const uint64_t base = (uint64_t)blockIdx.x * CENSUS_WORDS_PER_BLOCK;
+    uint32_t s = 0;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const uint64_t w = base + (uint64_t)k * 256 + threadIdx.x;
+        if (w < words) s += (uint32_t)__popc(census[w].x);
+    }
+    s = block_sum_256(s, lds);
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = s;
+}
+
+// one workgroup: block_sums -> exclusive offsets in place, the total behind them
+__global__ void __launch_bounds__(1024) census_top_kernel(uint32_t* block_sums, uint32_t nblocks) {
+    __shared__ uint32_t part[1024];
+    const uint32_t per = (nblocks + 1023u) / 1024u;
+    const uint32_t lo = threadIdx.x * per, hi = min(lo + per, nblocks);
+    uint32_t s = 0;
+    for (uint32_t i = lo; i < hi; ++i) s += block_sums[i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (int i = 0; i < 1024; ++i) { const uint32_t t = part[i]; part[i] = run; run += t; }
+        block_sums[nblocks] = run;
+    }
+    __syncthreads();
+    uint32_t run = part[threadIdx.x];
+    for (uint32_t i = lo; i < hi; ++i) { const uint32_t t = block_sums[i]; block_sums[i] = run; run += t; }
+}
+
+// census[w].below, and the ids themselves (ids == NULL: only the prefix)
+__global__ void __launch_bounds__(256) census_apply_kernel(uint2* census, uint64_t words, const uint32_t* __restrict__ block_sums, uint32_t* ids) {
+    __shared__ uint32_t wave_tot[4];
+    const uint64_t base = (uint64_t)blockIdx.x * CENSUS_WORDS_PER_BLOCK;
+    uint32_t run = block_sums[blockIdx.x];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int k = 0; k < 16; ++k) {                      // 256 consecutive words per round
+        const uint64_t w = base + (uint64_t)k * 256 + threadIdx.x;
+        const uint32_t bits = w < words ? census[w].x : 0u;
+        const uint32_t c = (uint32_t)__popc(bits);
+        uint32_t inc = c;                               // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off, 64); if (lane >= off) inc += t; }
+        if (lane == 63) wave_tot[wv] = inc;
+        __syncthreads();
+        uint32_t before = run;
+        for (int q = 0; q < wv; ++q) before += wave_tot[q];
+        const uint32_t round_total = wave_tot[0] + wave_tot[1] + wave_tot[2] + wave_tot[3];
+        const uint32_t below = before + inc - c;
+        if (w < words) {
+            census[w].y = below;
+            if (ids) {
+                uint32_t b = bits, at = below;
+                while (b) { const int bit = __ffs((int)b) - 1; ids[at++] = (uint32_t)(w << 5) + (uint32_t)bit; b &= b - 1u; }
+            }
+        }
+        run += round_total;
+        __syncthreads();
+    }
+}
+
+__device__ __forceinline__ uint32_t census_rank(const uint2* __restrict__ census, uint32_t v, uint32_t limit, uint32_t& missing) {
+    if (v > limit) { missing = 1u; return 0u; }
+    const uint2 e = census[v >> 5];
+    const uint32_t bit = 1u << (v & 31u);
+    if (!(e.x & bit)) missing = 1u;
+    return e.y + (uint32_t)__popc(e.x & (bit - 1u));
+}
+
+// out[p] = rank(vol[p]); *status |= 1 when a voxel holds an id the census does not know (a census from a list)
+template <typename T>
+__global__ void __launch_bounds__(256) census_rank_kernel(const T* __restrict__ vol, T* __restrict__ out, uint64_t n, uint64_t nvec,
+                                                          const uint2* __restrict__ census, uint32_t limit, uint32_t* status) {
+    constexpr int PER = 16 / (int)sizeof(T);
+    const uint4* v4 = reinterpret_cast<const uint4*>(vol);
+    uint4* o4 = reinterpret_cast<uint4*>(out);
+    uint32_t missing = 0u, prev = 0u, prev_rank = 0u;
+    bool have = false;
+    auto rank_of = [&](uint32_t v) {
+        if (!have || v != prev) { prev_rank = census_rank(census, v, limit, missing); prev = v; have = true; }
+        return prev_rank;
+    };
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint4 x = v4[i];
+        uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            if (sizeof(T) == 4) w[k] = rank_of(w[k]);
+            else { const uint32_t a = rank_of(w[k] & 0xffffu); const uint32_t b = rank_of(w[k] >> 16); w[k] = a | (b << 16); }
+        }
+        o4[i] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    for (uint64_t t = nvec * PER + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (uint64_t)gridDim.x * blockDim.x)
+        out[t] = (T)rank_of((uint32_t)vol[t]);
+    if (missing) atomicOr(status, 1u);
+}
+
+unsigned stream_blocks(uint64_t items) {
+    uint64_t b = (items + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace
+
+uint64_t census_words(uint32_t max_label) { return ((uint64_t)max_label >> 5) + 1; }
+uint64_t census_bytes(uint32_t max_label) { return census_words(max_label) * sizeof(uint2); }
+uint64_t census_scratch_bytes(uint32_t max_label) {
+    return ((census_words(max_label) + CENSUS_WORDS_PER_BLOCK - 1) / CENSUS_WORDS_PER_BLOCK + 1) * sizeof(uint32_t) + 16;
+}
+
+void launch_census_mark(hipStream_t s, const void* vol, int itemsize, uint64_t n, void* census) {
+    if (n == 0) return;
+    const uint64_t nvec = ((uintptr_t)vol & 15) ? 0 : n / (16 / itemsize);
+    const unsigned blocks = stream_blocks(nvec ? nvec : n);
+    if (itemsize == 2) hipLaunchKernelGGL(census_mark_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)vol, n, nvec, (uint2*)census);
+    else               hipLaunchKernelGGL(census_mark_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, (const uint32_t*)vol, n, nvec, (uint2*)census);
+}
+
+void launch_census_from_ids(hipStream_t s, const uint32_t* ids_dev, uint64_t n, void* census) {
+    if (n == 0) return;
+    hipLaunchKernelGGL(census_from_ids_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, ids_dev, n, (uint2*)census);
+}
+
+// the prefix counts of a marked census; `*total_dev` (inside scratch) receives the number of ids.  Call once with ids_out == NULL
+// to learn the total, again with the array to expand the ids (or once with an array known to be large enough).
+void launch_census_scan(hipStream_t s, void* census, uint32_t max_label, void* scratch, uint32_t* ids_out, uint32_t** total_dev) {
+    const uint64_t words = census_words(max_label);
+    const uint32_t nblocks = (uint32_t)((words + CENSUS_WORDS_PER_BLOCK - 1) / CENSUS_WORDS_PER_BLOCK);
+    uint32_t* block_sums = (uint32_t*)scratch;
+    hipLaunchKernelGGL(census_block_sums_kernel, dim3(nblocks), dim3(256), 0, s, (const uint2*)census, words, block_sums);
+    hipLaunchKernelGGL(census_top_kernel, dim3(1), dim3(1024), 0, s, block_sums, nblocks);
+    hipLaunchKernelGGL(census_apply_kernel, dim3(nblocks), dim3(256), 0, s, (uint2*)census, words, block_sums, ids_out);
+    if (total_dev) *total_dev = block_sums + nblocks;
+}
+
+void launch_census_rank(hipStream_t s, const void* vol, void* out, int itemsize, uint64_t n, const void* census, uint32_t max_label,
+                        uint32_t* status) {
+    if (n == 0) return;
+    const uint64_t nvec = (((uintptr_t)vol | (uintptr_t)out) & 15) ? 0 : n / (16 / itemsize);
+    const unsigned blocks = stream_blocks(nvec ? nvec : n);
+    if (itemsize == 2) hipLaunchKernelGGL(census_rank_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)vol, (uint16_t*)out, n, nvec, (const uint2*)census, max_label, status);
+    else               hipLaunchKernelGGL(census_rank_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, (const uint32_t*)vol, (uint32_t*)out, n, nvec, (const uint2*)census, max_label, status);
+}
+
+}  // namespace ta

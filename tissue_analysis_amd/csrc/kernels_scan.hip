@@ -28,6 +28,8 @@
 // the run = column of the voxel right of it, whose label is the closing label of the row's NEXT record).
 #include "ta_sweep_common.h"
 
+#include <type_traits>
+
 #include <hip/hip_ext.h>
 
 namespace ta {
@@ -626,6 +628,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // VGPRs + 13 pinned (two rows, the row above, the voxel to the left) = 95: FIVE waves per SIMD
 #define TA_PIN_ADJ2 82
 #define TA_CAP_ADJ2 78
+// TA_PLANES_IN_FLIGHT = 2 (experiment): a second landing zone behind the first, 82 + 27 = 109 registers, FOUR waves per SIMD
+#ifndef TA_PLANES_IN_FLIGHT
+#define TA_PLANES_IN_FLIGHT 1
+#endif
+#define TA_PIN_ADJ2B 96
 #define TA_CAP_MOM 72
 // the PADDED kernels (partial tiles of a volume whose rows are 16-byte aligned: interior-style loads, edge-style
 // semantics) carry more state: with adjacency 116 + 21 = 137 (three waves per SIMD), without 80 + 16 = 96 (five, like the
@@ -655,7 +662,9 @@ __device__ __forceinline__ void unpack_strip(const u32x4& x, uint32_t (&dst)[VPL
 // column to the left.  PINB: 0 = plain guarded loads (volumes whose rows are not 16-byte aligned), else the first of the
 // hand-pinned registers the plane in flight lands in.  EDGE with PINB != 0 is the PADDED variant: interior-style loads from
 // clamped addresses, the positions outside the volume overwritten with the filler when the plane lands.
-template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, typename LDS>
+// PINB2 != 0 (experiment, TA_PLANES_IN_FLIGHT = 2): a SECOND landing zone -- two planes in flight per wave, the plane loop
+// unrolled by two, `s_waitcnt vmcnt(4)` where the next plane's four loads stay in flight.
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, int PINB2, typename LDS>
 __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* kp, LDS& S, const int lane, const int w,
                                           const uint32_t c_tile0, const uint32_t b_tile0,
                                           const int32_t p_lo, const int32_t p_hi) {
@@ -735,12 +744,12 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     const uint32_t left_off = (uint32_t)(PAD && b_wave0 + (lane & (RB - 1)) >= n1 ? 0 : (lane & (RB - 1))) * rowbytes;    // (the VGPR offset of a load is unsigned)
     const int64_t plane_bytes = plane * (int64_t)sizeof(T);
     const char* next_row0 = reinterpret_cast<const char*>(vol + (int64_t)(has_prev ? p_lo - 1 : p_lo) * plane + b_base * n2 + c_tile0);
-    auto issue_plane = [&]() {                            // issues the plane at `next_row0` and steps it
+    auto issue_plane_to = [&](auto zone) {                // issues the plane at `next_row0` into a landing zone and steps it
         const char* row0 = next_row0;
 #ifndef TA_ABL_L2
         next_row0 += plane_bytes;
 #endif
-        using P = Pin<PINB ? PINB : TA_PIN_ADJ>;
+        using P = Pin<decltype(zone)::value>;
         P::template issue_strip<0>(lane_off, row0);
         P::template issue_strip<1>(lane_off, row_in[1] ? row0 + rowbytes : row0);
         if (RB > 2) {
@@ -755,6 +764,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             P::template issue_voxel<T, RB>(left_off, has_left ? row0 - sizeof(T) : row0);
         }
     };
+    auto issue_plane = [&]() { issue_plane_to(std::integral_constant<int, (PINB ? PINB : TA_PIN_ADJ)>{}); };
 
     // PADDED: what landed for positions outside the volume is overwritten with the filler; a REAL voxel equal to the
     // filler (0xFFFFFFFF in a uint32 volume: above any max_label) is reported like the plain edge loads report it
@@ -1037,7 +1047,33 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     //      issued into the registers it leaves, the landed one is processed.  (Measured and dropped: TWO planes in flight for
     //      the two-row tiles of uint16 volumes, in the two halves of the sixteen pinned registers -- C2 stayed at 0.070 ms:
     //      that kernel is bound by its instructions per voxel, not by the bytes it has in flight.)
-    {
+    auto top_drains = [&]() {
+        if constexpr (DRAIN_ALL) {
+            if (fcount >= (uint32_t)TA_FDRAIN) drain_face_groups<LDS>(kp, S, W, lane, fcount);
+            if (rcount > 64u) drain_run_group<MOM2, LDS>(kp, S, W, EDGE, lane, rcount, first_label);
+        }
+    };
+    if constexpr (PINB != 0 && PINB2 != 0) {
+        // two planes in flight: plane p lands from zone A (PINB) for even p - p_lo, from zone B (PINB2) for odd; each landing
+        // leaves the other zone's four loads in flight and re-issues its own zone two planes ahead
+        using ZA = std::integral_constant<int, PINB>;
+        using ZB = std::integral_constant<int, PINB2>;
+        if (p_lo + 1 < p_hi) issue_plane_to(ZB{});
+        for (int32_t p = p_lo; p < p_hi; p += 2) {
+            top_drains();
+            if (p + 1 < p_hi) Pin<PINB>::template landed_keep4<RB>(nraw, nup_raw, nxt_leftv);
+            else Pin<PINB>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+            if (p + 2 < p_hi) issue_plane_to(ZA{});
+            process_plane(p);
+            if (p + 1 < p_hi) {
+                top_drains();
+                if (p + 2 < p_hi) Pin<PINB2>::template landed_keep4<RB>(nraw, nup_raw, nxt_leftv);
+                else Pin<PINB2>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+                if (p + 3 < p_hi) issue_plane_to(ZB{});
+                process_plane(p + 1);
+            }
+        }
+    } else {
         for (int32_t p = p_lo; p < p_hi; ++p) {
             if constexpr (DRAIN_ALL) {
                 // the hot drains: between two planes a wave holds nothing but the plane before (and the next one is in flight)
@@ -1152,7 +1188,7 @@ __device__ __forceinline__ uint32_t claim_tile(uint32_t* queues, const uint32_t 
 
 // PERSIST: the workgroup walks tiles until the queues are empty: its tables are emptied by the flush itself, the flush's global
 // atomics are left in flight while the next tile starts, and no workgroup has to be launched (and waited out) per tile.
-template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, bool PERSIST = false>
+template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, bool PERSIST = false, int PINB2 = 0>
 __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanSplit& sp, const uint32_t wg0) {
     constexpr int NW = MOM2 ? 6 : 2;
     constexpr int TC = 64 * VPL, TB = WAVES * RB;
@@ -1224,7 +1260,7 @@ __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanS
         __syncthreads();
 
         if (p_lo < p_hi)
-            wave_scan<T, VPL, RB, ADJ, MOM2, EDGE, PINB>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
+            wave_scan<T, VPL, RB, ADJ, MOM2, EDGE, PINB, PINB2>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
         __syncthreads();
         // (everything the flush needs is re-read -- arguments from the kernarg segment, the tile origin from LDS --
         //  rather than kept in scarce SGPRs across the sweep)
@@ -1267,7 +1303,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_
 template <typename T, int VPL, int RB, bool MOM2>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ2))) scan_two_rows_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
     static_assert(RB == 2 && sizeof(T) == 4, "the 13-register landing zone holds two rows of a uint32 volume");
-    scan_kernel_body<T, VPL, RB, true, MOM2, false, TA_PIN_ADJ2, TA_PERSIST != 0>(A, sp, wg0);
+    scan_kernel_body<T, VPL, RB, true, MOM2, false, TA_PIN_ADJ2, TA_PERSIST != 0, (TA_PLANES_IN_FLIGHT == 2 ? TA_PIN_ADJ2B : 0)>(A, sp, wg0);
 }
 template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_MOM))) scan_noadj_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {

@@ -90,6 +90,13 @@ struct ta_ctx {
     int64_t a_origin = 0;
     int first_owned = 0;
 
+    // sparse label ids: the census of the volume's ids and the copy of the volume in their ranks (what the sweep then reads)
+    DevBuf census, census_ids, compact_vol;
+    uint32_t census_max = 0;            // ids 0 .. census_max have a bit
+    int64_t census_n = -1;              // ids present, -1 = no census
+    bool compact = false;               // per-label ROWS are ranks 0 .. census_n - 1; every label VALUE handed out is an id
+    std::vector<uint32_t> h_ids;        // rank -> id (host copy, compact mode)
+
     // accumulators
     DevBuf own_sums, own_boxes;
     uint64_t* sums = nullptr;
@@ -141,6 +148,14 @@ uint32_t* flags_dev(ta_ctx* c) { return (uint32_t*)c->small.p; }
 uint32_t* cursor_dev(ta_ctx* c) { return (uint32_t*)c->small.p + ta::NFLAGS; }
 uint32_t* maxlab_dev(ta_ctx* c) { return (uint32_t*)c->small.p + ta::NFLAGS + 1; }
 
+// the volume the sweep reads: the rank copy in compact mode
+const void* sweep_vol(const ta_ctx* c) { return c->compact ? c->compact_vol.p : c->vol; }
+
+void drop_census(ta_ctx* c) {
+    c->census_n = -1;
+    if (c->compact) { c->compact = false; c->extracted = c->checked = false; }
+}
+
 int use_device(ta_ctx* c) {
     TA_HIP(hipSetDevice(c->device));
     return TA_OK;
@@ -178,7 +193,7 @@ int auto_pair_log2(uint32_t max_label) {
 int run_extract(ta_ctx* c) {
     const uint64_t nlabels = (uint64_t)c->max_label + 1;
     ta::SweepArgs a;
-    a.vol = c->vol;
+    a.vol = sweep_vol(c);
     a.n0 = c->mdims[0]; a.n1 = c->mdims[1]; a.n2 = c->mdims[2];
     a.a_origin = c->a_origin;
     a.first_owned = c->first_owned;
@@ -194,8 +209,8 @@ int run_extract(ta_ctx* c) {
     // 16-byte loads: rows that are 16-byte aligned, or ANY rows of a volume the library uploaded itself (unaligned 16-byte
     // global loads are legal on gfx950 -- 6.2 TB/s from dword-aligned, 4.8 TB/s from odd addresses, measured -- and the
     // strip that straddles the end of the very last row reads into the slack ta_volume_set leaves behind the buffer)
-    a.vec_ok = ((((uintptr_t)c->vol & 15) == 0) && ((a.n2 * c->itemsize) % 16 == 0)) || (c->vol == c->owned_vol.p && c->owned_vol.p) ||
-               c->volume_slack >= 16;       // (an adopted buffer whose owner promises readable bytes behind it: TA_OPT_VOLUME_SLACK)
+    a.vec_ok = ((((uintptr_t)a.vol & 15) == 0) && ((a.n2 * c->itemsize) % 16 == 0)) || (a.vol == c->owned_vol.p && c->owned_vol.p) ||
+               c->compact || c->volume_slack >= 16;       // (an adopted buffer whose owner promises readable bytes behind it: TA_OPT_VOLUME_SLACK)
     a.max_label = c->max_label;
     a.sums = c->sums;
     a.boxes = c->boxes;
@@ -370,6 +385,7 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     c->wall_counts.release();
     c->wall_stage.release();
     c->wall_medians.release();
+    c->census.release(); c->census_ids.release(); c->compact_vol.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ring) if (e) (void)hipEventDestroy(e);
@@ -488,6 +504,7 @@ TA_API int ta_volume_set(ta_ctx* c, const void* host_ptr, int itemsize, const in
     TA_HIP(hipMemcpyAsync(c->owned_vol.p, host_ptr, bytes, hipMemcpyHostToDevice, c->stream));
     TA_HIP(hipStreamSynchronize(c->stream));   // the host buffer may be freed after return
     c->vol = c->owned_vol.p;
+    drop_census(c);
     c->auto_tile_shift = 0;
     c->wall_records = -1;
     c->wall_median_count = -1;
@@ -510,6 +527,7 @@ TA_API int ta_volume_set_device(ta_ctx* c, const void* dev_ptr, int itemsize, co
     if (a0_origin < 0) return fail(TA_EINVAL, "a0_origin must be >= 0");
     if (((uintptr_t)dev_ptr % itemsize) != 0) return fail(TA_EINVAL, "device pointer is not aligned to the label type");
     c->vol = dev_ptr;
+    drop_census(c);
     c->volume_slack = 0;
     c->auto_tile_shift = 0;
     c->wall_records = -1;
@@ -544,6 +562,7 @@ TA_API int ta_volume_relabel(ta_ctx* c, const uint32_t* lut, uint32_t lut_len) {
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     d.release();
     if (e != hipSuccess) return fail(TA_EHIP, "relabel: %s", hipGetErrorString(e));
+    drop_census(c);                 // (the ids changed: a compacted context goes back to dense rows until it is compacted again)
     c->extracted = c->checked = false;
     c->wall_median_count = -1;
     c->wall_records = -1;           // the staged wall records carry the OLD labels: a fetch must ask for a fresh count
@@ -919,6 +938,119 @@ TA_API int ta_volume_max_label(ta_ctx* c, uint32_t* max_label) {
     return TA_OK;
 }
 
+// ---- sparse label ids -------------------------------------------------------------------------------------------
+namespace {
+// census of `ids` (host, ascending, unique; NULL: of the resident volume itself) on the context; leaves census_n / census_ids
+int build_census(ta_ctx* c, const uint32_t* ids, uint32_t n_ids) {
+    int rc;
+    const uint64_t nvox = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2];
+    uint32_t top = 0;
+    if (ids) {
+        for (uint32_t i = 1; i < n_ids; ++i)
+            if (ids[i] <= ids[i - 1]) return fail(TA_EINVAL, "ids must be ascending and unique (ids[%u]=%u after %u)", i, ids[i], ids[i - 1]);
+        top = n_ids ? ids[n_ids - 1] : 0u;
+    } else {
+        ta::launch_max_label(c->stream, c->vol, c->itemsize, nvox, maxlab_dev(c));
+        TA_HIP(hipMemcpyAsync(&top, maxlab_dev(c), sizeof(top), hipMemcpyDeviceToHost, c->stream));
+        TA_HIP(hipStreamSynchronize(c->stream));
+    }
+    c->census_n = -1;
+    if ((rc = c->census.reserve(ta::census_bytes(top))) != TA_OK) return rc;
+    DevBuf scratch, staged;
+    if ((rc = scratch.reserve(ta::census_scratch_bytes(top))) != TA_OK) return rc;
+    hipError_t e = hipMemsetAsync(c->census.p, 0, ta::census_bytes(top), c->stream);
+    if (e == hipSuccess && ids && n_ids) {
+        if ((rc = staged.reserve((uint64_t)n_ids * 4)) != TA_OK) { scratch.release(); return rc; }
+        e = hipMemcpyAsync(staged.p, ids, (uint64_t)n_ids * 4, hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess) ta::launch_census_from_ids(c->stream, (const uint32_t*)staged.p, n_ids, c->census.p);
+    } else if (e == hipSuccess && !ids) {
+        ta::launch_census_mark(c->stream, c->vol, c->itemsize, nvox, c->census.p);
+    }
+    uint32_t* total_dev = nullptr;
+    uint32_t total = 0;
+    if (e == hipSuccess) {
+        ta::launch_census_scan(c->stream, c->census.p, top, scratch.p, nullptr, &total_dev);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&total, total_dev, sizeof(total), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e == hipSuccess && total) {
+        rc = c->census_ids.reserve((uint64_t)total * 4);
+        if (rc != TA_OK) { scratch.release(); staged.release(); return rc; }
+        ta::launch_census_scan(c->stream, c->census.p, top, scratch.p, (uint32_t*)c->census_ids.p, nullptr);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    }
+    scratch.release();
+    staged.release();
+    if (e != hipSuccess) return fail(TA_EHIP, "label census: %s", hipGetErrorString(e));
+    c->census_max = top;
+    c->census_n = (int64_t)total;
+    return TA_OK;
+}
+}  // namespace
+
+TA_API int ta_volume_label_census(ta_ctx* c, uint32_t* max_label, uint32_t* n_present) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    if (c->compact) return fail(TA_EINVAL, "the context is compacted: its census is the one it was compacted with");
+    if ((rc = build_census(c, nullptr, 0)) != TA_OK) return rc;
+    if (max_label) *max_label = c->census_max;
+    if (n_present) *n_present = (uint32_t)c->census_n;
+    return TA_OK;
+}
+
+TA_API int ta_label_census_get(ta_ctx* c, uint32_t* ids) {
+    if (!c || !ids) return fail(TA_EINVAL, "NULL argument");
+    if (c->census_n < 0) return fail(TA_EINVAL, "no label census on this context");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    if (c->census_n == 0) return TA_OK;
+    TA_HIP(hipMemcpyAsync(ids, c->census_ids.p, (uint64_t)c->census_n * 4, hipMemcpyDeviceToHost, c->stream));
+    TA_HIP(hipStreamSynchronize(c->stream));
+    return TA_OK;
+}
+
+TA_API int ta_volume_compact_labels(ta_ctx* c, const uint32_t* ids, uint32_t n_ids, uint32_t* n_rows) {
+    if (!c || (!ids && n_ids)) return fail(TA_EINVAL, "NULL argument");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    c->compact = false;
+    c->extracted = c->checked = false;
+    if (ids || c->census_n < 0)
+        if ((rc = build_census(c, ids, n_ids)) != TA_OK) return rc;
+    if (c->census_n >= (1ll << 28)) return fail(TA_ERANGE, "%lld label ids are present: too many for per-label rows", (long long)c->census_n);
+    const uint64_t nvox = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2];
+    if ((rc = c->compact_vol.reserve(nvox * c->itemsize + 64)) != TA_OK) return rc;
+    uint32_t status = 0;
+    hipError_t e = hipMemsetAsync(maxlab_dev(c), 0, sizeof(uint32_t), c->stream);       // (the word is free between max-label passes)
+    if (e == hipSuccess) {
+        ta::launch_census_rank(c->stream, c->vol, c->compact_vol.p, c->itemsize, nvox, c->census.p, c->census_max, maxlab_dev(c));
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&status, maxlab_dev(c), sizeof(status), hipMemcpyDeviceToHost, c->stream);
+    try { c->h_ids.resize((size_t)c->census_n); } catch (...) { return fail(TA_ENOMEM, "out of host memory"); }
+    if (e == hipSuccess && c->census_n)
+        e = hipMemcpyAsync(c->h_ids.data(), c->census_ids.p, (uint64_t)c->census_n * 4, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return fail(TA_EHIP, "compact labels: %s", hipGetErrorString(e));
+    if (status) return fail(TA_ERANGE, "the volume holds a label id that is not in the list it was to be compacted with");
+    c->compact = true;
+    c->auto_tile_shift = 0;
+    if (n_rows) *n_rows = (uint32_t)c->census_n;
+    return TA_OK;
+}
+
+TA_API int ta_volume_is_compact(ta_ctx* c, int* compact, uint32_t* n_rows) {
+    if (!c || !compact) return fail(TA_EINVAL, "NULL argument");
+    *compact = c->compact ? 1 : 0;
+    if (n_rows) *n_rows = c->compact ? (uint32_t)c->census_n : 0u;
+    return TA_OK;
+}
+
 TA_API int ta_volume_plane_events(ta_ctx* c, uint64_t* events) {
     if (!c || !events) return fail(TA_EINVAL, "NULL argument");
     if (!c->vol) return fail(TA_EINVAL, "no volume set");
@@ -1077,9 +1209,9 @@ TA_API int ta_adjacency_get(ta_ctx* c, uint32_t* lo, uint32_t* hi, uint64_t* fac
             char* p = (char*)buf.p;
             uint64_t* ks = (uint64_t*)p; p += kb;
             uint64_t* fo = (uint64_t*)p; p += n * 24;
-            const bool has_voxel = c->vol && c->mdims[0] - c->first_owned > 0 && c->mdims[1] > 0 && c->mdims[2] > 0;
+            const bool has_voxel = sweep_vol(c) && c->mdims[0] - c->first_owned > 0 && c->mdims[1] > 0 && c->mdims[2] > 0;
             hipError_t e = ta::launch_pairs_sort(c->stream, (const uint64_t*)c->out_keys.p, (const uint64_t*)c->out_faces.p, n, c->max_label,
-                                                 p, ks, fo, has_voxel ? c->vol : nullptr, c->itemsize,
+                                                 p, ks, fo, has_voxel ? sweep_vol(c) : nullptr, c->itemsize,
                                                  (int64_t)c->first_owned * c->mdims[1] * c->mdims[2]);
             // (keys and faces sit back to back in the sort's output: one copy)
             if (e == hipSuccess) e = hipMemcpyAsync(c->h_pairs.p, ks, n * 32, hipMemcpyDeviceToHost, c->stream);
@@ -1091,8 +1223,18 @@ TA_API int ta_adjacency_get(ta_ctx* c, uint32_t* lo, uint32_t* hi, uint64_t* fac
     const bool identity = c->perm[0] == 0 && c->perm[1] == 1 && c->perm[2] == 2;
     const uint64_t* h_keys = (const uint64_t*)c->h_pairs.p;
     const uint64_t* h_faces = h_keys + n;
-    if (lo) for (uint64_t i = 0; i < n; ++i) lo[i] = (uint32_t)(h_keys[i] >> 32);
-    if (hi) for (uint64_t i = 0; i < n; ++i) hi[i] = (uint32_t)(h_keys[i] & 0xffffffffu);
+    if (c->compact) {               // rows are ranks, label values are ids (order-preserving: the list stays sorted)
+        const uint64_t nid = c->h_ids.size();
+        for (uint64_t i = 0; i < n; ++i) {
+            const uint64_t a = h_keys[i] >> 32, b = h_keys[i] & 0xffffffffu;
+            if (a >= nid || b >= nid) return fail(TA_ERANGE, "adjacency holds rank %llu, the census has %llu ids", (unsigned long long)std::max(a, b), (unsigned long long)nid);
+            if (lo) lo[i] = c->h_ids[a];
+            if (hi) hi[i] = c->h_ids[b];
+        }
+    } else {
+        if (lo) for (uint64_t i = 0; i < n; ++i) lo[i] = (uint32_t)(h_keys[i] >> 32);
+        if (hi) for (uint64_t i = 0; i < n; ++i) hi[i] = (uint32_t)(h_keys[i] & 0xffffffffu);
+    }
     if (faces && identity && n) memcpy(faces, h_faces, n * 3 * sizeof(uint64_t));      // C-ordered input: a plain copy
     else if (faces) for (uint64_t i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) faces[3 * i + c->perm[k]] = h_faces[3 * i + k];
     return TA_OK;

@@ -84,6 +84,16 @@ uint64_t pairs_sort_scratch_bytes(uint64_t n, uint32_t max_label);
 hipError_t launch_pairs_sort(hipStream_t s, const uint64_t* keys, const uint64_t* faces, uint64_t n, uint32_t max_label, void* scratch,
                              uint64_t* keys_out, uint64_t* faces_out, const void* vol, int itemsize, int64_t corner);
 
+// kernels_census.hip -- the label ids a volume holds (device np.unique) and the volume rewritten in their ranks
+uint64_t census_words(uint32_t max_label);
+uint64_t census_bytes(uint32_t max_label);              // { bits, ids below } per 32 ids
+uint64_t census_scratch_bytes(uint32_t max_label);
+void launch_census_mark(hipStream_t s, const void* vol, int itemsize, uint64_t n, void* census);
+void launch_census_from_ids(hipStream_t s, const uint32_t* ids_dev, uint64_t n, void* census);
+void launch_census_scan(hipStream_t s, void* census, uint32_t max_label, void* scratch, uint32_t* ids_out, uint32_t** total_dev);
+void launch_census_rank(hipStream_t s, const void* vol, void* out, int itemsize, uint64_t n, const void* census, uint32_t max_label,
+                        uint32_t* status);
+
 // kernels_basic.hip (continued)
 void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3], int64_t a_begin,
                   int64_t a_count, const int32_t* seeds_dev, const int32_t grid[3],

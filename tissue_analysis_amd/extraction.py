@@ -86,8 +86,9 @@ class NeighborRows(Mapping):
         if not self._has(label):
             raise KeyError(label)
         ptr = self.indptr
-        if 0 <= label < ptr.size - 1:
-            return self.indices[ptr[label]:ptr[label + 1]].tolist()
+        row = self._x.row_of(label)
+        if 0 <= row < ptr.size - 1:
+            return self.indices[ptr[row]:ptr[row + 1]].tolist()
         return []
 
     def __contains__(self, label):
@@ -100,12 +101,41 @@ class NeighborRows(Mapping):
         return int(self.keys_array.size)
 
 
+class BoxesByLabel(object):
+    """`nd.find_objects(image)` of an image whose ids are sparse: entry k is the box of label k + 1 (None when the image
+    does not hold it), made when it is looked up -- the list itself would have max_label entries."""
+
+    def __init__(self, extraction):
+        self._x = extraction
+
+    def __len__(self):
+        return self._x.max_label
+
+    def __getitem__(self, k):
+        if isinstance(k, slice):
+            return [self[i] for i in range(*k.indices(len(self)))]
+        k = int(k)
+        if k < 0:
+            k += len(self)
+        if not 0 <= k < len(self):
+            raise IndexError("list index out of range")
+        return self._x.bbox_slices(k + 1)
+
+    def __iter__(self):
+        return (self[k] for k in range(len(self)))
+
+
 class Extraction(object):
-    """Exact integer result of one sweep (rows 0..max_label) + adjacency COO sorted by (lo, hi)."""
+    """Exact integer result of one sweep + adjacency COO sorted by (lo, hi).  Rows 0..max_label, one per label id -- or, for
+    a volume whose ids are SPARSE (`ids` given: the ascending ids the volume holds, SIA:358-364 np.unique takes any), one row
+    per id in that order; every method takes and answers label IDS either way, `rows_of` is the only place that knows."""
 
     def __init__(self, shape, max_label, count, bbox, sum1, sum2, pair_lo, pair_hi, pair_faces,
-                 timing=None):
+                 timing=None, ids=None):
         self.shape = tuple(int(s) for s in shape)
+        self.ids = None if ids is None else np.asarray(ids, dtype=np.int64)
+        if self.ids is not None:
+            max_label = int(self.ids[-1]) if self.ids.size else 0
         self.max_label = int(max_label)
         self.count = np.asarray(count, dtype=np.uint64)
         self.bbox = np.asarray(bbox, dtype=np.int32).reshape(-1, 6)
@@ -115,6 +145,9 @@ class Extraction(object):
         self.pair_hi = np.asarray(pair_hi, dtype=np.uint32)
         self.pair_faces = np.asarray(pair_faces, dtype=np.uint64).reshape(-1, 3)
         self.timing = timing
+        self.nrows = int(self.count.shape[0])
+        if self.ids is not None and self.ids.size != self.nrows:
+            raise ValueError("%d ids for %d rows" % (self.ids.size, self.nrows))
         self._csr = None
         self._derived = {}
 
@@ -122,12 +155,53 @@ class Extraction(object):
     def from_arrays(cls, shape, arrays, timing=None):
         """Build from a dict with the C-ABI array names (what tests / distributed merges hold)."""
         return cls(shape, arrays["max_label"], arrays["count"], arrays["bbox"], arrays["sum1"],
-                   arrays["sum2"], arrays["pair_lo"], arrays["pair_hi"], arrays["pair_faces"], timing)
+                   arrays["sum2"], arrays["pair_lo"], arrays["pair_hi"], arrays["pair_faces"], timing, arrays.get("ids"))
 
     def as_arrays(self):
-        return dict(max_label=self.max_label, count=self.count, bbox=self.bbox, sum1=self.sum1,
-                    sum2=self.sum2, pair_lo=self.pair_lo, pair_hi=self.pair_hi,
-                    pair_faces=self.pair_faces)
+        out = dict(max_label=self.max_label, count=self.count, bbox=self.bbox, sum1=self.sum1,
+                   sum2=self.sum2, pair_lo=self.pair_lo, pair_hi=self.pair_hi,
+                   pair_faces=self.pair_faces)
+        if self.ids is not None:
+            out["ids"] = self.ids
+        return out
+
+    # ------------------------------------------------------------------ label id -> row
+    @property
+    def sparse(self):
+        return self.ids is not None
+
+    def rows_of(self, labels, missing=None):
+        """int64 row of every label id.  An id without a row: IndexError (like indexing the dense rows beyond max_label), or
+        `missing` when that is given (callers that answer zeros for unknown labels pass the index of a zero row)."""
+        idx = np.asarray(labels, dtype=np.int64)
+        if self.ids is None:
+            if missing is None:
+                return idx
+            return np.where((idx >= 0) & (idx < self.nrows), idx, missing)
+        if self.ids.size == 0:
+            pos = np.zeros(idx.shape, dtype=np.int64)
+            ok = np.zeros(idx.shape, dtype=bool)
+        else:
+            pos = np.minimum(np.searchsorted(self.ids, idx), self.ids.size - 1)
+            ok = self.ids[pos] == idx
+        if missing is None:
+            if not ok.all():
+                raise IndexError("label ids %s are not in the image" % np.asarray(idx)[~ok][:5].tolist())
+            return pos
+        return np.where(ok, pos, missing)
+
+    def row_of(self, label):
+        """Row of ONE label id, -1 when it has none."""
+        label = int(label)
+        if self.ids is None:
+            return label if 0 <= label < self.nrows else -1
+        k = int(np.searchsorted(self.ids, label))
+        return k if k < self.ids.size and self.ids[k] == label else -1
+
+    def labels_of(self, rows):
+        """The label ids of rows (the inverse of rows_of)."""
+        rows = np.asarray(rows, dtype=np.int64)
+        return rows if self.ids is None else self.ids[rows]
 
     def _cached(self, name, make):
         if name not in self._derived:
@@ -137,7 +211,7 @@ class Extraction(object):
     # ------------------------------------------------------------------ labels / boxes
     def present(self):
         """Ascending ids of the labels that own at least one voxel."""
-        return self._cached("present", lambda: np.nonzero(self.count)[0])
+        return self._cached("present", lambda: self.labels_of(np.nonzero(self.count)[0]))
 
     @property
     def lo(self):
@@ -161,23 +235,47 @@ class Extraction(object):
         s = tuple(float(v) for v in face_surface)
         return self._cached(("area", s), lambda: f[:, 0] * s[0] + f[:, 1] * s[1] + f[:, 2] * s[2])
 
+    @property
+    def lo_rows(self):
+        """The rows of the pair list's labels (the ids themselves unless the ids are sparse)."""
+        return self.lo if self.ids is None else self._cached("lo_rows", lambda: self.rows_of(self.lo))
+
+    @property
+    def hi_rows(self):
+        return self.hi if self.ids is None else self._cached("hi_rows", lambda: self.rows_of(self.hi))
+
+    def _row_degrees(self):
+        n = max(self.nrows, self.max_label + 1 if self.ids is None else 0) + 1
+        return self._cached("degree", lambda: np.bincount(self.lo_rows, minlength=n) + np.bincount(self.hi_rows, minlength=n))
+
     def degrees(self):
-        """int64 [max_label + 2]: how many labels share a face with each label."""
-        return self._cached("degree", lambda: np.bincount(self.lo, minlength=self.max_label + 2)
-                            + np.bincount(self.hi, minlength=self.max_label + 2))
+        """int64 [max_label + 2]: how many labels share a face with each label (dense ids only: see degrees_of)."""
+        if self.ids is not None:
+            raise TypeError("degrees() is indexed by label id: use degrees_of(labels) when the ids are sparse")
+        return self._row_degrees()
+
+    def degrees_of(self, labels):
+        """int64 [n]: how many labels share a face with each of `labels` (0 for an id the image does not hold)."""
+        deg = self._row_degrees()
+        return deg[self.rows_of(labels, missing=deg.size - 1)]
 
     def has(self, label):
-        return 0 <= label <= self.max_label and self.count[label] > 0
+        row = self.row_of(label)
+        return row >= 0 and self.count[row] > 0
 
     def bbox_slices(self, label):
         """(slice, slice, slice) like nd.find_objects, or None when the label is absent."""
-        if not self.has(label):
+        row = self.row_of(label)
+        if row < 0 or not self.count[row] > 0:
             return None
-        b = self.bbox[label]
+        b = self.bbox[row]
         return tuple(slice(int(b[d]), int(b[3 + d])) for d in range(3))
 
     def bbox_slices_upto(self, top):
-        """[bbox_slices(1), ..., bbox_slices(top)] in one pass (python ints from two .tolist() calls)."""
+        """[bbox_slices(1), ..., bbox_slices(top)] in one pass (python ints from two .tolist() calls); sparse ids: the same
+        sequence made on demand."""
+        if self.ids is not None:
+            return BoxesByLabel(self)
         top = min(int(top), self.max_label)
         rows = self.bbox[1:top + 1].tolist()
         have = (self.count[1:top + 1] > 0).tolist()
@@ -192,22 +290,26 @@ class Extraction(object):
         ptr, dst, _ = self._adjacency_csr()
         flat, p = self._cached("csr_lists", lambda: (dst.tolist(), ptr.tolist()))
         n = len(p) - 1
-        return dict((l, flat[p[l]:p[l + 1]] if 0 <= l < n else []) for l in labels)
+        if self.ids is None:
+            return dict((l, flat[p[l]:p[l + 1]] if 0 <= l < n else []) for l in labels)
+        labels = list(labels)
+        rows = self.rows_of(labels, missing=-1).tolist() if labels else []
+        return dict((l, flat[p[r]:p[r + 1]] if 0 <= r < n else []) for l, r in zip(labels, rows))
 
     # ------------------------------------------------------------------ moments
     def volumes(self, labels):
-        return self.count[np.asarray(labels, dtype=np.int64)].astype(np.float64)
+        return self.count[self.rows_of(labels)].astype(np.float64)
 
     def barycenters(self, labels):
         """float64 [n, 3], voxel units."""
-        idx = np.asarray(labels, dtype=np.int64)
+        idx = self.rows_of(labels)
         n = self.count[idx].astype(np.float64)
         with np.errstate(invalid="ignore", divide="ignore"):
             return self.sum1[idx].astype(np.float64) / n[:, None]
 
     def covariances(self, labels):
         """float64 [n, 3, 3] = sum (p - com)(p - com)^T / max(3, N)."""
-        idx = np.asarray(labels, dtype=np.int64)
+        idx = self.rows_of(labels)
         N = self.count[idx].astype(np.int64)
         o = np.where(self.bbox[idx, :3] < 0, 0, self.bbox[idx, :3]).astype(np.int64)   # bbox origin
         s1 = self.sum1[idx].astype(np.int64)
@@ -240,46 +342,53 @@ class Extraction(object):
 
     # ------------------------------------------------------------------ adjacency
     def _adjacency_csr(self):
+        """(ptr [rows + 1], dst, pid): the pair list as CSR over the ROWS; dst holds label ids, ascending inside a row."""
         if self._csr is None:
-            lo, hi = self.lo, self.hi
+            lo, hi = self.lo_rows, self.hi_rows
             src = np.concatenate([lo, hi])
-            dst = np.concatenate([hi, lo])
+            dst = np.concatenate([hi, lo])            # (rows: the order of the rows is the order of the ids)
             pid = np.concatenate([np.arange(lo.size), np.arange(lo.size)])
-            nrows = max(self.max_label + 1, int(src.max()) + 1 if src.size else 0)
+            nrows = max(self.nrows if self.ids is not None else self.max_label + 1, int(src.max()) + 1 if src.size else 0)
             order = np.argsort(src * np.int64(nrows) + dst, kind="stable")
             ptr = np.zeros(nrows + 1, dtype=np.int64)
             np.cumsum(np.bincount(src, minlength=nrows), out=ptr[1:])
-            self._csr = (ptr, dst[order], pid[order])
+            self._csr = (ptr, self.labels_of(dst[order]), pid[order])
         return self._csr
 
     def neighbors_of(self, label):
         """Ascending int list of the labels sharing at least one voxel face with `label`."""
         ptr, dst, _ = self._adjacency_csr()
-        if label < 0 or label + 1 >= ptr.size:
+        row = self.row_of(label) if self.ids is not None else int(label)
+        if row < 0 or row + 1 >= ptr.size:
             return []
-        return [int(v) for v in dst[ptr[label]:ptr[label + 1]]]
+        return [int(v) for v in dst[ptr[row]:ptr[row + 1]]]
 
     def surface_faces(self, labels):
         """uint64 [n, 3]: per-axis number of voxel faces each label shares with ANY other label (faces on the border
         of the volume belong to no wall and are not counted): the row sums of the adjacency."""
+        top = self.nrows if self.ids is not None else self.max_label + 1                   # (index of the zero row)
+
         def rows():
-            n = self.max_label + 2
-            return np.stack([(np.bincount(self.lo, weights=self.faces[:, d], minlength=n)
-                              + np.bincount(self.hi, weights=self.faces[:, d], minlength=n)) for d in range(3)],
+            n = top + 1
+            return np.stack([(np.bincount(self.lo_rows, weights=self.faces[:, d], minlength=n)
+                              + np.bincount(self.hi_rows, weights=self.faces[:, d], minlength=n)) for d in range(3)],
                             axis=1).astype(np.uint64)            # (float64 sums of integers far below 2^53: exact)
         out = self._cached("surface_faces", rows)
+        if self.ids is not None:
+            return out[self.rows_of(labels, missing=top)]
         idx = np.asarray(labels, dtype=np.int64)
-        idx = np.where((idx >= 0) & (idx <= self.max_label), idx, self.max_label + 1)     # unknown labels: the zero row
+        idx = np.where((idx >= 0) & (idx <= self.max_label), idx, top)                    # unknown labels: the zero row
         return out[idx]
 
     def faces_between(self, label, others):
         """uint64 [len(others), 3]: per-axis shared-face counts of (label, other); 0 when not adjacent."""
         ptr, dst, pid = self._adjacency_csr()
         out = np.zeros((len(others), 3), dtype=np.uint64)
-        if label < 0 or label + 1 >= ptr.size:
+        r = self.row_of(label) if self.ids is not None else int(label)
+        if r < 0 or r + 1 >= ptr.size:
             return out
-        row = dst[ptr[label]:ptr[label + 1]]
-        rid = pid[ptr[label]:ptr[label + 1]]
+        row = dst[ptr[r]:ptr[r + 1]]
+        rid = pid[ptr[r]:ptr[r + 1]]
         pos = np.searchsorted(row, np.asarray(others, dtype=np.int64))
         for i, (p, o) in enumerate(zip(pos, others)):
             if p < row.size and row[p] == o:
@@ -291,10 +400,33 @@ def full_mask():
     return _capi.F_ALL
 
 
-def extract_resident(ctx, shape, features=_capi.F_ALL, max_label=None):
-    """Run the sweep on the volume already resident in `ctx` and fetch the result."""
-    if max_label is None:
+SPARSE_FROM = 1 << 18          # ids below this cost at most 27 MB of rows: not worth a census
+DENSE_ROW_LIMIT = 1 << 28      # ta_extract's own bound on max_label
+
+
+def wants_compaction(max_label, n_present):
+    """Sparse ids: more than 8 ids of room per label present (and enough rows for that to matter), or beyond the dense rows."""
+    return max_label >= DENSE_ROW_LIMIT or (max_label >= SPARSE_FROM and max_label + 1 > 8 * max(int(n_present), 1))
+
+
+def extract_resident(ctx, shape, features=_capi.F_ALL, max_label=None, sparse=None):
+    """Run the sweep on the volume already resident in `ctx` and fetch the result.  sparse: None = decide from the volume
+    (`wants_compaction`: one max-label pass, and a census of the ids when that is large), True / False = as told; an explicit
+    `max_label` means dense rows 0..max_label, as before."""
+    ids = None
+    if ctx.is_compact():
+        ids = ctx.compact_ids()
+    elif max_label is None and sparse is not False:
+        top = ctx.max_label()
+        if sparse or top >= SPARSE_FROM:
+            top, present = ctx.label_census()
+            if sparse or wants_compaction(top, present.size):
+                ids = ctx.compact_labels()
+        max_label = top
+    elif max_label is None:
         max_label = ctx.max_label()
+    if ids is not None:
+        max_label = max(int(ids.size) - 1, 0)
     ctx.extract(features, max_label)
     count, bbox, sum1, sum2 = ctx.labels()
     if _capi.feature_mask(features) & _capi.F_ADJACENCY:
@@ -302,7 +434,7 @@ def extract_resident(ctx, shape, features=_capi.F_ALL, max_label=None):
     else:
         lo = hi = np.zeros(0, dtype=np.uint32)
         faces = np.zeros((0, 3), dtype=np.uint64)
-    return Extraction(shape, max_label, count, bbox, sum1, sum2, lo, hi, faces, ctx.timing())
+    return Extraction(shape, max_label, count, bbox, sum1, sum2, lo, hi, faces, ctx.timing(), ids=ids)
 
 
 def _as_label_volume(array):
