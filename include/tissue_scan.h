@@ -124,6 +124,8 @@ TA_API int ta_volume_max_label(ta_ctx* ctx, uint32_t* max_label);
  *   out (ta_adjacency_get) is an id; ta_label_census_get is the rank -> id table.  ids == NULL: the census of this volume;
  *   otherwise a HOST list, ascending and unique, that must cover the volume (TA_ERANGE if it does not): the union over the ranks
  *   of a partitioned volume, so that every slab ranks alike and the device-side adjacency exchange works in rank space.
+ *   The label TABLES a caller hands in are per-label rows too: in a compacted context ta_volume_relabel takes one entry per
+ *   rank (lut_len == n_rows, the entries are ids: v -> lut[rank(v)]) and ta_volume_map answers out[p] = lut[rank(V[p])].
  *   More than 2^28 - 1 ids present => TA_ERANGE.  A new volume or ta_volume_relabel ends the compacted state.
  * New in TA_ABI_VERSION 4. */
 TA_API int ta_volume_label_census(ta_ctx* ctx, uint32_t* max_label, uint32_t* n_present);

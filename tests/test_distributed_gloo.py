@@ -227,3 +227,35 @@ def test_only_pairs_a_slab_face_can_split_need_to_travel(world, dims, n_cells, s
     assert sorted(merged) == sorted(want)
     assert all(np.array_equal(merged[k], want[k]) for k in want)
     assert len(travelling) < len(want)                           # (something did stay at home)
+
+
+def _union_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from tissue_analysis_amd import distributed as tad
+        mine = [np.array([0, 7, 1 << 31, (1 << 32) - 1], dtype=np.uint32), np.array([7, 9], dtype=np.uint32),
+                np.zeros(0, dtype=np.uint32)][rank]
+        ids = tad.union_of_ids(mine, dist.group.WORLD)
+        q.put((rank, ids.dtype == np.uint32 and ids.tolist() == [0, 7, 9, 1 << 31, (1 << 32) - 1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_union_of_ids_over_three_ranks():
+    """The id table the slabs of a volume with sparse ids compact with: the same ascending union on every rank, whatever each
+    rank's own list holds (one of them holds nothing)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29300 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_union_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(3)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in results), results

@@ -153,8 +153,16 @@ def test_relabel_and_a_new_volume_end_the_compacted_state(gpu_ctx):
     gpu_ctx.set_volume(vol)
     gpu_ctx.compact_labels()
     assert gpu_ctx.is_compact()
-    gpu_ctx.relabel(np.arange(4, dtype=np.uint32))
+    with pytest.raises(_capi.TissueScanError):                  # a compacted context relabels through one entry per RANK
+        gpu_ctx.relabel(np.arange(4, dtype=np.uint32))
+    ids = gpu_ctx.compact_ids()
+    table = ids.copy()
+    table[3] = ids[2]                                           # the fourth id is fused into the third
+    gpu_ctx.relabel(table)
     assert not gpu_ctx.is_compact()
+    back = np.zeros_like(vol)
+    gpu_ctx.get_volume(back)
+    assert np.array_equal(back, np.where(vol == ids[3], ids[2], vol))
     gpu_ctx.compact_labels()
     gpu_ctx.set_volume(vol)
     assert not gpu_ctx.is_compact()
@@ -172,3 +180,49 @@ def test_resident_volume_picks_the_sparse_path_by_itself():
         assert np.isin(lo, ids).all() and len(t) > 0
     finally:
         rv.close()
+
+
+def test_the_analysis_class_end_to_end_on_ids_near_2_31():
+    """SpatialImageAnalysis on a uint32 image whose ids are spread to 2^31: every answer equals that of the same image with
+    small ids (ids translated), including the passes that rewrite the image through a per-label table (fuse / remove labels,
+    property images): in a compacted context the table has one entry per rank."""
+    from tissue_analysis_amd import DICT, SpatialImage, SpatialImageAnalysis3D
+    dense = voronoi((20, 24, 96), 25, 11, np.uint32)
+    rng = np.random.default_rng(11)
+    old = np.unique(dense)
+    lut = np.arange(int(old.max()) + 1, dtype=np.uint64)
+    moved = old[old > 1]
+    lut[moved] = np.sort(rng.choice(np.arange(1 << 20, (1 << 31) + 500, 977, dtype=np.uint64), size=moved.size, replace=False))
+    vol = lut[dense].astype(np.uint32)                                  # (order-preserving here: min(labels) translates)
+    t = dict((int(k), int(lut[k])) for k in old)
+    a = SpatialImageAnalysis3D(SpatialImage(vol.copy()), ignoredlabels=0, return_type=DICT, background=1)
+    b = SpatialImageAnalysis3D(SpatialImage(dense.copy()), ignoredlabels=0, return_type=DICT, background=1)
+    assert a.extraction.sparse and not b.extraction.sparse
+    assert a.labels() == [t[l] for l in b.labels()]
+    va, vb = a.volume(), b.volume()
+    assert all(va[t[l]] == vb[l] for l in b.labels())
+    na, nb = a.neighbors(), b.neighbors()
+    assert all(na[t[l]] == [t[n] for n in nb[l]] for l in b.labels())
+    wa, wb = a.wall_areas(), b.wall_areas()
+    assert len(wa) == len(wb) and all(wa[(t[i], t[j])] == w for (i, j), w in wb.items())
+    assert a.boundingbox(t[b.labels()[3]]) == b.boundingbox(b.labels()[3])
+    assert a.cell_first_layer() == [t[l] for l in b.cell_first_layer()]
+    # property image: one value per label
+    prop = dict((l, (7 * l) % 251 + 2) for l in b.labels())
+    pa = a.property_image(dict((t[l], v) for l, v in prop.items()), dtype=np.uint16)
+    pb = b.property_image(prop, dtype=np.uint16)
+    assert np.array_equal(np.asarray(pa), np.asarray(pb))
+    # fuse three cells, then remove two others: the images stay translations of each other, and so do the new sweeps
+    trio = b.labels()[4:7]
+    a.fuse_labels_in_image([t[l] for l in trio], verbose=False)
+    b.fuse_labels_in_image(list(trio), verbose=False)
+    gone = b.labels()[8:10]
+    a.remove_labels_from_image([t[l] for l in gone], verbose=False)
+    b.remove_labels_from_image(list(gone), verbose=False)
+    assert np.array_equal(np.asarray(a.image), lut[np.asarray(b.image)].astype(np.uint32))
+    assert a.extraction.sparse and a.labels() == [t[l] for l in b.labels()]
+    va, vb = a.volume(), b.volume()
+    assert all(va[t[l]] == vb[l] for l in b.labels())
+    # the wall voxels and the voxel layers never see ranks
+    la, lb = a.voxel_first_layer(), b.voxel_first_layer()
+    assert np.array_equal(np.asarray(la), lut[np.asarray(lb)].astype(np.uint32))

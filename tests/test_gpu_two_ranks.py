@@ -292,3 +292,74 @@ def test_a_range_error_on_one_rank_is_raised_on_every_rank():
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(r[1] for r in results), results
+
+
+def _sparse_worker(rank, world, port, dims, n_cells, seed, depth, reduce, q):
+    """SPARSE ids over two slabs: every rank takes the census of its own slab on the device, the ranks agree on the union of
+    the ids and compact with it, so that an id has the same row on both; the exchange then runs in rank space."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from oracle import onepass_c
+        from tissue_analysis_amd import device as dev, distributed as tad, synth
+        whole = synth.voronoi_labels(dims, n_cells, seed, np.uint32)
+        rng = np.random.default_rng(seed)
+        old = np.unique(whole)
+        lut = np.zeros(int(old.max()) + 1, dtype=np.uint64)
+        lut[old] = rng.choice(np.arange(5, (1 << 32) - 1, 104729, dtype=np.uint64), size=old.size, replace=False)   # (not in order)
+        whole = lut[whole].astype(np.uint32)
+        ctx = dev.torch_context(0)
+        lo, hi = tad.slab_range(dims[0], world, rank)
+        halo = 1 if lo > 0 else 0
+        vol = torch.from_numpy(whole[lo - halo:hi].copy()).to("cuda:0")
+        ctx.set_volume_device(vol.data_ptr(), 4, vol.shape, a0_origin=lo, has_low_halo=bool(halo), keep=vol)
+        top, mine = ctx.label_census()
+        ids = tad.union_of_ids(mine, dist.group.WORLD)
+        census_ok = np.array_equal(mine, np.unique(whole[lo - halo:hi])) and np.array_equal(ids, np.unique(whole))
+        if depth > 1:
+            job = tad.PipelinedSlabJob(vol, 4, a_origin=lo, has_low_halo=bool(halo), max_label=0, features=31,
+                                       group=dist.group.WORLD, device=0, depth=depth, reduce=reduce, ids=ids)
+            for _ in range(3):
+                job.step()
+        else:
+            job = tad.SlabJob(ctx, vol, 4, a_origin=lo, has_low_halo=bool(halo), max_label=0, features=31,
+                              group=dist.group.WORLD, device=0, reduce=reduce, ids=ids)
+            job.step()
+            job.step()
+        got = job.result_arrays()
+        uniq, inv = np.unique(whole, return_inverse=True)
+        want = onepass_c.extract(inv.reshape(whole.shape).astype(np.uint32), max_label=uniq.size - 1)
+        want["pair_lo"] = uniq[np.asarray(want["pair_lo"], dtype=np.int64)]
+        want["pair_hi"] = uniq[np.asarray(want["pair_hi"], dtype=np.int64)]
+        bad = [k for k in ("count", "bbox", "sum1", "sum2", "pair_lo", "pair_hi", "pair_faces")
+               if not (np.asarray(got[k]).shape == np.asarray(want[k]).shape and np.array_equal(got[k], want[k]))]
+        if not np.array_equal(got["ids"], uniq.astype(np.int64)):
+            bad.append("ids")
+        if not census_ok:
+            bad.append("census")
+        q.put((rank, not bad, bad))
+        if depth > 1:
+            job.close()
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("depth,reduce", [(1, "all"), (2, "scatter")])
+def test_two_ranks_with_sparse_ids_agree_on_the_rows(depth, reduce):
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29400 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_sparse_worker, args=(r, world, port, (37, 40, 264), 50, 67, depth, reduce, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in results), results

@@ -475,13 +475,15 @@ void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const ui
 // with bounding-box crops in the reference).  map_kernel: to an output image of another word size
 // (PSI:207-221 create_property_image), labels beyond the table get `fill`.
 template <typename T>
-__global__ void __launch_bounds__(256) relabel_kernel(T* vol, uint64_t n, uint64_t nvec,
+__global__ void __launch_bounds__(256) relabel_kernel(const T* src, T* vol, uint64_t n, uint64_t nvec,
                                                       const uint32_t* __restrict__ lut, uint32_t lut_len) {
+    // src == vol: in place.  src = the volume's RANK copy (a compacted context): the table has one entry per rank.
     constexpr int PER = 16 / (int)sizeof(T);
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
     uint4* v4 = reinterpret_cast<uint4*>(vol);
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nvec;
          i += (uint64_t)gridDim.x * blockDim.x) {
-        uint4 x = v4[i];
+        uint4 x = s4[i];
         uint32_t w[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
@@ -499,19 +501,19 @@ __global__ void __launch_bounds__(256) relabel_kernel(T* vol, uint64_t n, uint64
     // tail: fewer than PER voxels, or the whole volume when the buffer is not 16-byte aligned (nvec = 0)
     for (uint64_t t = nvec * PER + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < n;
          t += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t v = vol[t];
+        const uint32_t v = src[t];
         if (v < lut_len) vol[t] = (T)lut[v];
     }
 }
 
-void launch_relabel(hipStream_t s, void* vol, int itemsize, uint64_t n, const uint32_t* lut, uint32_t lut_len) {
+void launch_relabel(hipStream_t s, const void* src, void* vol, int itemsize, uint64_t n, const uint32_t* lut, uint32_t lut_len) {
     if (n == 0) return;
-    const uint64_t nvec = ((uintptr_t)vol & 15) ? 0 : n / (16 / itemsize);
+    const uint64_t nvec = (((uintptr_t)vol | (uintptr_t)src) & 15) ? 0 : n / (16 / itemsize);
     uint64_t blocks = ((nvec ? nvec : n) + 255) / 256;
     if (blocks < 1) blocks = 1;
     if (blocks > 16384) blocks = 16384;
-    if (itemsize == 2) hipLaunchKernelGGL(relabel_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (uint16_t*)vol, n, nvec, lut, lut_len);
-    else               hipLaunchKernelGGL(relabel_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s, (uint32_t*)vol, n, nvec, lut, lut_len);
+    if (itemsize == 2) hipLaunchKernelGGL(relabel_kernel<uint16_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint16_t*)src, (uint16_t*)vol, n, nvec, lut, lut_len);
+    else               hipLaunchKernelGGL(relabel_kernel<uint32_t>, dim3((unsigned)blocks), dim3(256), 0, s, (const uint32_t*)src, (uint32_t*)vol, n, nvec, lut, lut_len);
 }
 
 template <typename TI, typename TO>

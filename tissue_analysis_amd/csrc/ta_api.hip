@@ -545,6 +545,8 @@ TA_API int ta_volume_relabel(ta_ctx* c, const uint32_t* lut, uint32_t lut_len) {
     if (!c || (!lut && lut_len)) return fail(TA_EINVAL, "NULL argument");
     if (!c->vol) return fail(TA_EINVAL, "no volume set");
     if (c->first_owned) return fail(TA_EINVAL, "cannot relabel a slab that carries a halo plane");
+    if (c->compact && lut_len != (uint32_t)c->census_n)
+        return fail(TA_EINVAL, "a compacted context relabels through one entry per rank: %u entries for %lld ranks", lut_len, (long long)c->census_n);
     if (c->itemsize == 2)
         for (uint32_t i = 0; i < lut_len; ++i)
             if (lut[i] > 0xFFFFu) return fail(TA_ERANGE, "lut[%u]=%u does not fit the uint16 volume", i, lut[i]);
@@ -555,7 +557,7 @@ TA_API int ta_volume_relabel(ta_ctx* c, const uint32_t* lut, uint32_t lut_len) {
     if ((rc = d.reserve((uint64_t)lut_len * 4)) != TA_OK) return rc;
     hipError_t e = hipMemcpyAsync(d.p, lut, (uint64_t)lut_len * 4, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        ta::launch_relabel(c->stream, const_cast<void*>(c->vol), c->itemsize,
+        ta::launch_relabel(c->stream, sweep_vol(c), const_cast<void*>(c->vol), c->itemsize,
                            (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2], (const uint32_t*)d.p, lut_len);
         e = hipGetLastError();
     }
@@ -598,7 +600,7 @@ TA_API int ta_volume_map(ta_ctx* c, const void* lut, uint32_t lut_len, const voi
     hipError_t e = hipSuccess;
     if (lut_len) e = hipMemcpyAsync(dl.p, lut, (uint64_t)lut_len * out_itemsize, hipMemcpyHostToDevice, c->stream);
     if (e == hipSuccess) {
-        ta::launch_map(c->stream, c->vol, c->itemsize, dout.p, out_itemsize, n, dl.p, lut_len, fillw);
+        ta::launch_map(c->stream, sweep_vol(c), c->itemsize, dout.p, out_itemsize, n, dl.p, lut_len, fillw);     // (compacted: lut[rank])
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipMemcpyAsync(host_dst, dout.p, n * out_itemsize, hipMemcpyDeviceToHost, c->stream);

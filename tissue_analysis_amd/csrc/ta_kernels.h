@@ -26,7 +26,7 @@ void launch_pairs_collect_hot(hipStream_t s, const PairTable& pt, uint64_t* out_
                               const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows);
 void launch_hot_reduce(hipStream_t s, const SweepArgs& a, int itemsize, const uint64_t* hot_rows, uint32_t nrows,
                        uint32_t* publish = nullptr, int nwords = 0);
-void launch_relabel(hipStream_t s, void* vol, int itemsize, uint64_t n, const uint32_t* lut, uint32_t lut_len);
+void launch_relabel(hipStream_t s, const void* src, void* vol, int itemsize, uint64_t n, const uint32_t* lut, uint32_t lut_len);
 void launch_map(hipStream_t s, const void* vol, int itemsize, void* out, int out_itemsize, uint64_t n,
                 const void* lut, uint32_t lut_len, uint64_t fill);
 void launch_read_probe(hipStream_t s, const void* p, uint64_t bytes, uint32_t* sink);

@@ -123,6 +123,26 @@ def allgather_pairs(keys, faces, group=None):
     return kall, fall, max(m, 1)
 
 
+def union_of_ids(ids, group=None, device=None):
+    """COLLECTIVE: the ascending union of every rank's label ids (numpy, e.g. `ctx.label_census()[1]` of the rank's slab): the
+    table all ranks of a partitioned volume with SPARSE ids compact with (`SlabJob(ids=...)`), so that an id has the same row
+    everywhere.  A few thousand ids per rank: one padded all-gather."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    on = device if (device is not None and dist.get_backend(group) == "nccl") else "cpu"
+    mine = torch.from_numpy(np.ascontiguousarray(ids, dtype=np.int64)).to(on)
+    sizes = torch.zeros(world, dtype=torch.int64, device=on)
+    dist.all_gather_into_tensor(sizes, torch.tensor([mine.numel()], dtype=torch.int64, device=on), group=group)
+    m = max(int(sizes.max().item()), 1)
+    pad = torch.full((m,), -1, dtype=torch.int64, device=on)
+    pad[:mine.numel()] = mine
+    every = torch.empty((world * m,), dtype=torch.int64, device=on)
+    dist.all_gather_into_tensor(every, pad, group=group)
+    every = every.cpu().numpy()
+    return np.unique(every[every >= 0]).astype(np.uint32)
+
+
 def sums_shard_rows(nrows, world):
     """Rows of the per-label sums every rank keeps after a reduce-scatter: the table is padded to world x this."""
     return -(-int(nrows) // int(world))
@@ -243,8 +263,11 @@ class SlabJob(object):
     """
 
     def __init__(self, ctx, vol_tensor, itemsize, a_origin, has_low_halo, max_label, features,
-                 group=None, device=0, exchange_capacity=None, stream=None, reduce="all"):
-        """reduce: "all" -- both tables all-reduced, every rank holds the global rows after step(); "scatter" -- the sums
+                 group=None, device=0, exchange_capacity=None, stream=None, reduce="all", ids=None):
+        """ids: SPARSE label ids -- the ascending table of ALL ids of the partitioned volume (`union_of_ids`, the same on every
+        rank): the slab is swept in the ranks of that table, every per-label row of this job (sums, boxes, the exchange) is a
+        rank, `max_label` is ignored (rows = len(ids)) and result_arrays() answers pairs in ids and carries the table.
+        reduce: "all" -- both tables all-reduced, every rank holds the global rows after step(); "scatter" -- the sums
         (8 of the 10.4 MB at 100k labels) are reduce-SCATTERED: a rank keeps the global rows of its share of the labels in
         `sums_shard` (and its own slab's partial rows in `sums`), only the boxes, which decide which pairs travel, are
         all-reduced; result_counts() / result_arrays() gather the shards (collective)."""
@@ -263,6 +286,9 @@ class SlabJob(object):
             ctx.set_stream(stream.cuda_stream)
         self.has_low_halo = bool(has_low_halo)
         self.a_origin = int(a_origin)           # global index of the first OWNED plane
+        self.ids = None if ids is None else np.ascontiguousarray(ids, dtype=np.uint32)
+        if self.ids is not None:
+            max_label = max(int(self.ids.size) - 1, 0)
         self.max_label, self.features = int(max_label), features
         dev = "cuda:%d" % device
         rows = self.max_label + 1
@@ -277,6 +303,8 @@ class SlabJob(object):
         self.boxes = torch.zeros((self.max_label + 1, 6), dtype=torch.int32, device=dev)
         ctx.set_volume_device(vol_tensor.data_ptr(), itemsize, vol_tensor.shape, a0_origin=a_origin,
                               has_low_halo=has_low_halo, keep=vol_tensor)
+        if self.ids is not None:
+            ctx.compact_labels(self.ids)
         ctx.bind_accumulators(self.sums.data_ptr(), self.boxes.data_ptr(), self.max_label,
                               keep=(self.sums, self.boxes))
         self._torch = torch
@@ -287,6 +315,13 @@ class SlabJob(object):
 
     def owned_view(self):
         return self.vol[1:] if self.has_low_halo else self.vol
+
+    def _pair_rows(self, allow_partial=False):
+        """The context's pair list with its labels as ROWS of this job's tables (a compacted context answers in ids)."""
+        lo, hi, faces = self.ctx.adjacency(allow_partial=allow_partial)
+        if self.ids is not None:
+            lo, hi = np.searchsorted(self.ids, lo).astype(np.uint32), np.searchsorted(self.ids, hi).astype(np.uint32)
+        return lo, hi, faces
 
     # -- adjacency exchange ------------------------------------------------------------------
     def _adjacency_wanted(self):
@@ -350,7 +385,7 @@ class SlabJob(object):
         lo, hi = self._slab_planes()
         status, err, ntravel = self._OK, None, 0
         try:
-            plo, phi, _ = self.ctx.adjacency()
+            plo, phi, _ = self._pair_rows()
             excl = slab_exclusive(self.boxes.cpu().numpy(), lo, hi)
             inside = (plo <= self.max_label) & (phi <= self.max_label)
             travels = ~inside | ~(excl[np.minimum(plo, self.max_label)] | excl[np.minimum(phi, self.max_label)])
@@ -497,13 +532,17 @@ class SlabJob(object):
                                  second_moments=bool(_capi.feature_mask(self.features) & _capi.F_MOMENT2))
         out["max_label"] = self.max_label
         if _capi.feature_mask(self.features) & _capi.F_ADJACENCY:
-            lo, hi, faces = self.ctx.adjacency(allow_partial=True)
+            lo, hi, faces = self._pair_rows(allow_partial=True)
             if self._adjacency_wanted():
                 lo, hi, faces = self._global_pairs(lo, hi, faces)
+            if self.ids is not None:
+                lo, hi = self.ids[lo], self.ids[hi]
         else:
             lo = hi = np.zeros(0, dtype=np.uint32)
             faces = np.zeros((0, 3), dtype=np.uint64)
         out.update(pair_lo=lo, pair_hi=hi, pair_faces=faces)
+        if self.ids is not None:
+            out["ids"] = self.ids.astype(np.int64)
         return out
 
 
@@ -515,7 +554,7 @@ class PipelinedSlabJob(object):
     for and validates every step in flight, in issue order."""
 
     def __init__(self, vol_tensor, itemsize, a_origin, has_low_halo, max_label, features, group=None,
-                 device=0, depth=2, tile_planes=0, reduce="all"):
+                 device=0, depth=2, tile_planes=0, reduce="all", ids=None):
         import torch
         from . import _capi
         torch.cuda.synchronize(device)            # the slab was written on another stream
@@ -527,7 +566,7 @@ class PipelinedSlabJob(object):
                 ctx.set_option(_capi.OPT_TILE_PLANES, tile_planes)
             with torch.cuda.stream(stream):
                 self.jobs.append(SlabJob(ctx, vol_tensor, itemsize, a_origin, has_low_halo, max_label, features,
-                                         group=group, device=device, stream=stream, reduce=reduce))
+                                         group=group, device=device, stream=stream, reduce=reduce, ids=ids))
         self._issued = 0
 
     @property

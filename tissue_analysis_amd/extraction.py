@@ -493,10 +493,12 @@ class ResidentVolume(object):
         self.ms["upload"] = (time.perf_counter() - t0) * 1e3
         self.uploads += 1
 
-    def extract(self, features=_capi.F_ALL, max_label=None):
+    def extract(self, features=_capi.F_ALL, max_label=None, sparse=None):
+        """One sweep of the resident volume.  Ids that are sparse (`wants_compaction`) are swept in their ranks: the
+        Extraction then has one row per id present (`.ids`) instead of rows 0..max_label; sparse=False insists on dense rows."""
         import time
         t0 = time.perf_counter()
-        x = extract_resident(self.ctx, self.host.shape, features, max_label)
+        x = extract_resident(self.ctx, self.host.shape, features, max_label, sparse)
         self.ms["extract"] = (time.perf_counter() - t0) * 1e3
         return x
 
@@ -543,8 +545,8 @@ class ResidentVolume(object):
 
 
 def extract_volume(array, features=_capi.F_ALL, device=0, context=None, max_label=None,
-                   impl=None, tile_planes=None):
-    """Upload `array` (uint16/uint32, any dense layout) and run the fused sweep on the GPU."""
+                   impl=None, tile_planes=None, sparse=None):
+    """Upload `array` (uint16/uint32, any dense layout) and run the fused sweep on the GPU (`sparse`: see extract_resident)."""
     a = np.asarray(array)
     if a.ndim == 2:
         a = a[:, :, None]
@@ -556,7 +558,7 @@ def extract_volume(array, features=_capi.F_ALL, device=0, context=None, max_labe
         if tile_planes is not None:
             ctx.set_option(_capi.OPT_TILE_PLANES, tile_planes)
         ctx.set_volume(a)
-        return extract_resident(ctx, a.shape, features, max_label)
+        return extract_resident(ctx, a.shape, features, max_label, sparse)
     finally:
         if own:
             ctx.close()

@@ -33,7 +33,7 @@ from __future__ import annotations
 
 import numpy as np
 
-from .property_graph import PropertyGraph
+from .property_graph import PropertyGraph, _Index
 from .spatial_image_analysis import AbstractSpatialImageAnalysis, DICT, SpatialImageAnalysis
 
 _INT = (int, np.integer)
@@ -81,13 +81,10 @@ class _PairView(object):
         surf = np.asarray(analysis.get_voxel_face_surface(), dtype=np.float64)
         self.area_real = faces[:, 0] * surf[0] + faces[:, 1] * surf[1] + faces[:, 2] * surf[2]
         self.area_voxels = faces[:, 0] + faces[:, 1] + faces[:, 2]
-        top = int(max(x.max_label, int(self.hi.max()) if self.hi.size else 0)) + 1
         ids = np.asarray(vertex_ids, dtype=np.int64)
-        inside = (ids >= 0) & (ids <= top)
-        self.row_of = np.full(top + 1, -1, dtype=np.int64)               # label -> vertex row
-        self.row_of[ids[inside]] = np.flatnonzero(inside)
-        self.lo_in = self.row_of[self.lo] >= 0
-        self.hi_in = self.row_of[self.hi] >= 0
+        self.row_of = _Index(ids).rows                                   # labels -> vertex rows (-1: not a vertex)
+        self.lo_in = self.row_of(self.lo) >= 0
+        self.hi_in = self.row_of(self.hi) >= 0
         self.kept = np.ones(self.lo.size, dtype=bool) if min_contact_area is None else ~(self.area_real < min_contact_area)
 
     def area(self, real):
@@ -111,15 +108,15 @@ def _wall_median_columns(graph, analysis, pairs, background):
 
     V, E = graph.nb_vertices(), graph.nb_edges()
     edge_value, edge_valid = np.zeros((E, 3), dtype=np.int64), np.zeros(E, dtype=bool)
-    both = (pairs.row_of[lo] >= 0) & (pairs.row_of[hi] >= 0)
+    both = (pairs.row_of(lo) >= 0) & (pairs.row_of(hi) >= 0)
     ekey = (graph.edge_sources.astype(np.uint64) << np.uint64(32)) | graph.edge_targets.astype(np.uint64)
     erow = np.searchsorted(ekey, ((lo[both].astype(np.uint64) << np.uint64(32)) | hi[both].astype(np.uint64)))
     edge_value[erow], edge_valid[erow] = chosen[both], True
     graph.set_edge_column('wall_median', edge_value, edge_valid, _show_point)
     for name, first in (('epidermis_wall_median', 1), ('unlabelled_wall_median', 0)):
         value, valid = np.zeros((V, 3), dtype=np.int64), np.zeros(V, dtype=bool)
-        sel = (lo == first) & (pairs.row_of[hi] >= 0)
-        value[pairs.row_of[hi[sel]]], valid[pairs.row_of[hi[sel]]] = chosen[sel], True
+        sel = (lo == first) & (pairs.row_of(hi) >= 0)
+        value[pairs.row_of(hi[sel])], valid[pairs.row_of(hi[sel])] = chosen[sel], True
         graph.set_vertex_column(name, value, valid, _show_point)
 
 
@@ -134,8 +131,10 @@ def tissue_tables(analysis, labels, background, properties, property_as_real=Tru
     graph.set_vertex_column('label', ids.copy())
     graph.add_graph_property("units", dict())
     V = ids.size
-    known = (ids >= 0) & (ids <= x.max_label)
-    rows = np.where(known, ids, 0)                                         # accumulator rows (row 0 stands in for unknown ids)
+    rows = x.rows_of(ids, missing=-1)                                      # accumulator rows (sparse ids: not the ids)
+    known = rows >= 0
+    rows = np.where(known, rows, 0)                                        # (row 0 stands in for unknown ids)
+    standin = np.where(known, ids, x.labels_of(0) if x.nrows else 0)       # ... as a label, for the methods that take labels
     present = known & (x.count[rows] > 0)
     # volume / barycenter / inertia go through `label_request`, which drops what the analysis ignores (SIA:387-414)
     ignored = np.fromiter(analysis.ignoredlabels(), dtype=np.int64, count=len(analysis.ignoredlabels()))
@@ -155,13 +154,13 @@ def tissue_tables(analysis, labels, background, properties, property_as_real=Tru
         graph.set_vertex_column('volume', volume * (vs[0] * vs[1] * vs[2]) if real else volume, asked)
     with_barycenter = 'barycenter' in properties
     if with_barycenter:
-        com = x.barycenters(rows)
+        com = x.barycenters(standin)
         graph.set_vertex_column('barycenter', com * vs if real else com, asked)
 
     bg_rows, bg_partner = pairs.partners_of(-1 if background is None else int(background))
-    touches = pairs.row_of[bg_partner] >= 0                                # requested labels sharing a face with the background
+    touches = pairs.row_of(bg_partner) >= 0                                # requested labels sharing a face with the background
     l1 = np.zeros(V, dtype=bool)
-    l1[pairs.row_of[bg_partner[touches]]] = True
+    l1[pairs.row_of(bg_partner[touches])] = True
     if 'L1' in properties:
         graph.set_vertex_column('L1', l1)
     if 'border' in properties:
@@ -171,7 +170,7 @@ def tissue_tables(analysis, labels, background, properties, property_as_real=Tru
         border[hit[hit >= 0]] = True
         graph.set_vertex_column('border', border)
     if 'inertia_axis' in properties:
-        axes, values = x.inertia(rows)
+        axes, values = x.inertia(standin)
         if with_barycenter and asked.any():                                # TGI:165: the barycentres sit in the `real` slot
             values = values * np.linalg.norm(axes * vs, axis=2)
         graph.set_vertex_column('inertia_axis', axes, asked, _show_axes)
@@ -184,10 +183,10 @@ def tissue_tables(analysis, labels, background, properties, property_as_real=Tru
         # whose outer label is the LARGER one: the reference sums them with `wall_areas`, which skips n <= label (SIA:988)
         one_end = pairs.kept & pairs.lo_in & ~pairs.hi_in & (pairs.hi != (-1 if background is None else int(background)))
         graph.set_vertex_column('unlabelled_wall_surface',
-                                np.bincount(pairs.row_of[pairs.lo[one_end]], weights=area[one_end], minlength=V))
+                                np.bincount(pairs.row_of(pairs.lo[one_end]), weights=area[one_end], minlength=V))
     if 'epidermis_surface' in properties:
         value = np.zeros(V, dtype=np.float64)
-        value[pairs.row_of[bg_partner[touches]]] = pairs.area(real)[bg_rows[touches]]
+        value[pairs.row_of(bg_partner[touches])] = pairs.area(real)[bg_rows[touches]]
         graph.set_vertex_column('epidermis_surface', value, l1)
     if 'wall_median' in properties:
         _wall_median_columns(graph, analysis, pairs, background)

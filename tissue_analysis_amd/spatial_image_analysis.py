@@ -167,6 +167,16 @@ class AbstractSpatialImageAnalysis(object):
             self._rv = ResidentVolume(np.asarray(self.image), device=self._device)
         return self._rv
 
+    def _resident_rows(self):
+        """The resident volume in the state its label tables (one entry per ROW of the sweep) need: compacted with the ids of
+        the extraction when those are sparse -- a lookup table over ids up to 2^32 is not something to build."""
+        rv = self._resident()
+        if self._x.sparse and not rv.ctx.is_compact():
+            rv.ctx.compact_labels(self._x.ids)
+        elif not self._x.sparse and rv.ctx.is_compact():
+            raise RuntimeError("the resident volume is compacted but the extraction of this analysis has dense rows")
+        return rv
+
     def _sweep(self):
         return self._resident().extract(_capi.F_ALL)
 
@@ -275,7 +285,11 @@ class AbstractSpatialImageAnalysis(object):
     def center_of_mass(self, labels=None, real=True, verbose=False):
         labels = self.label_request(labels)
         idx = np.asarray(labels, dtype=np.int64)
-        com = self._x.barycenters(np.where((idx >= 0) & (idx <= self._x.max_label), idx, 0)) if idx.size else np.zeros((0, 3))
+        if idx.size:                                 # (an id the image does not hold -- label_request printed it -- gets row 0's)
+            known = self._x.rows_of(idx, missing=-1) >= 0
+            com = self._x.barycenters(np.where(known, idx, self._x.labels_of(0)))
+        else:
+            com = np.zeros((0, 3))
         if len(self._center_of_mass) < len(labels):                  # the reference's cache, voxel units (SIA:471)
             self._center_of_mass.update(zip(labels, com))
         if real:
@@ -314,7 +328,7 @@ class AbstractSpatialImageAnalysis(object):
             idx = np.asarray(labels, dtype=np.int64)
             if idx.size and (idx.min() < 1 or idx.max() > self._x.max_label):
                 raise IndexError("list index out of range")
-            box = self._x.bbox[idx]
+            box = self._x.bbox[self._x.rows_of(idx)]
             return box * np.tile(np.asarray(self._voxelsize, dtype=np.float64), 2) if real else box
         boxes = self._bbox_list()
         if isinstance(labels, list):
@@ -404,9 +418,7 @@ class AbstractSpatialImageAnalysis(object):
                 idx = np.asarray(keys, dtype=np.int64)
             else:
                 idx = np.asarray(labels, dtype=np.int64)
-            degree = self._x.degrees()
-            known = (idx >= 0) & (idx < degree.size)
-            return np.where(known, degree[np.where(known, idx, 0)], 0)
+            return self._x.degrees_of(idx)
         nei = self.neighbors(labels, min_contact_area, real_area, verbose)
         if isinstance(nei, dict):
             return dict((k, len(v)) for k, v in nei.items())
@@ -442,9 +454,12 @@ class AbstractSpatialImageAnalysis(object):
             x = self._x
             nei = self.neighbors()
             keys = np.fromiter(nei.keys(), dtype=np.int64, count=len(nei))
-            is_key = np.zeros(max(x.max_label + 2, int(keys.max()) + 1 if keys.size else 0), dtype=bool)
-            is_key[keys] = True
-            sel = np.flatnonzero(is_key[x.lo])
+            if x.sparse:
+                sel = np.flatnonzero(np.isin(x.lo, keys))
+            else:
+                is_key = np.zeros(max(x.max_label + 2, int(keys.max()) + 1 if keys.size else 0), dtype=bool)
+                is_key[keys] = True
+                sel = np.flatnonzero(is_key[x.lo])
             area = x.pair_areas(self.get_voxel_face_surface() if real else None)[sel]
             if self.return_type == NPLIST:
                 return np.stack([x.lo[sel], x.hi[sel]], axis=1), area
@@ -673,14 +688,15 @@ class AbstractSpatialImageAnalysis(object):
     # The reference leaves its caches (_labels, _bbox, _neighbors ...) stale after these calls; here the
     # relabelled volume is swept again in the same upload, so every later answer describes the new image.
     def _relabel_image(self, mapping):
-        rv = self._resident()
+        rv = self._resident_rows()
         top = np.iinfo(rv.host.dtype).max
-        lut = np.arange(self._x.max_label + 1, dtype=np.uint32)
+        lut = self._x.labels_of(np.arange(self._x.nrows)).astype(np.uint32)       # one entry per ROW: the row's own id
         for old, new in mapping.items():
             if not (0 <= int(new) <= top):
                 raise ValueError("value %r does not fit the image dtype %s" % (new, rv.host.dtype))
-            if 0 <= int(old) <= self._x.max_label:
-                lut[int(old)] = int(new)
+            row = self._x.row_of(old)
+            if row >= 0:
+                lut[row] = int(new)
         x = rv.relabel(lut)                       # resident volume and rv.host are relabelled; no new upload
         img = np.asarray(self.image)
         target = img if img.ndim == 3 else img[:, :, None]
@@ -734,13 +750,14 @@ class AbstractSpatialImageAnalysis(object):
         if bg is None:
             raise ValueError("property_image needs the background label")
         dtype = np.dtype(dtype)
-        lut = np.full(self._x.max_label + 1, bg, dtype=np.float64)
+        lut = np.full(self._x.nrows, bg, dtype=np.float64)                        # one entry per ROW of the sweep
         for l, v in property_dict.items():
-            if 0 <= int(l) <= self._x.max_label and int(l) != bg:
-                lut[int(l)] = v
+            row = self._x.row_of(l)
+            if row >= 0 and int(l) != bg:
+                lut[row] = v
         with np.errstate(invalid="ignore"):
             lut = lut.astype(dtype)
-        out = self._resident().map(lut, np.array(bg).astype(dtype))
+        out = self._resident_rows().map(lut, np.array(bg).astype(dtype))
         if np.asarray(self.image).ndim == 2:
             out = out[:, :, 0]
         return SpatialImage(out, voxelsize=getattr(self.image, "voxelsize", None))
@@ -791,7 +808,7 @@ class SpatialImageAnalysis3D(AbstractSpatialImageAnalysis):
         if present.size == 0:
             return []
         if d > 0:    # (image[-0:] is the whole image in the reference's slicing: distance 0 names every label)
-            box = x.bbox[present]
+            box = x.bbox[x.rows_of(present)]
             shape = np.asarray(x.shape, dtype=np.int64)
             present = present[(box[:, :3] < d).any(axis=1) | (box[:, 3:] > shape - d).any(axis=1)]
         if self._background is not None:
