@@ -961,12 +961,13 @@ int build_census(ta_ctx* c, const uint32_t* ids, uint32_t n_ids) {
     DevBuf scratch, staged;
     if ((rc = scratch.reserve(ta::census_scratch_bytes(top))) != TA_OK) return rc;
     hipError_t e = hipMemsetAsync(c->census.p, 0, ta::census_bytes(top), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(scratch.p, 0, ta::census_scratch_bytes(top), c->stream);
     if (e == hipSuccess && ids && n_ids) {
         if ((rc = staged.reserve((uint64_t)n_ids * 4)) != TA_OK) { scratch.release(); return rc; }
         e = hipMemcpyAsync(staged.p, ids, (uint64_t)n_ids * 4, hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess) ta::launch_census_from_ids(c->stream, (const uint32_t*)staged.p, n_ids, c->census.p);
+        if (e == hipSuccess) ta::launch_census_from_ids(c->stream, (const uint32_t*)staged.p, n_ids, c->census.p, scratch.p, top);
     } else if (e == hipSuccess && !ids) {
-        ta::launch_census_mark(c->stream, c->vol, c->itemsize, nvox, c->census.p);
+        ta::launch_census_mark(c->stream, c->vol, c->itemsize, nvox, c->mdims[2], c->census.p, scratch.p, top);
     }
     uint32_t* total_dev = nullptr;
     uint32_t total = 0;

@@ -88,8 +88,9 @@ hipError_t launch_pairs_sort(hipStream_t s, const uint64_t* keys, const uint64_t
 uint64_t census_words(uint32_t max_label);
 uint64_t census_bytes(uint32_t max_label);              // { bits, ids below } per 32 ids
 uint64_t census_scratch_bytes(uint32_t max_label);
-void launch_census_mark(hipStream_t s, const void* vol, int itemsize, uint64_t n, void* census);
-void launch_census_from_ids(hipStream_t s, const uint32_t* ids_dev, uint64_t n, void* census);
+void launch_census_mark(hipStream_t s, const void* vol, int itemsize, uint64_t n, int64_t row_len, void* census, void* scratch,
+                        uint32_t max_label);
+void launch_census_from_ids(hipStream_t s, const uint32_t* ids_dev, uint64_t n, void* census, void* scratch, uint32_t max_label);
 void launch_census_scan(hipStream_t s, void* census, uint32_t max_label, void* scratch, uint32_t* ids_out, uint32_t** total_dev);
 void launch_census_rank(hipStream_t s, const void* vol, void* out, int itemsize, uint64_t n, const void* census, uint32_t max_label,
                         uint32_t* status);
