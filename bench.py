@@ -442,6 +442,39 @@ def main():
                 del vol_w, lo_w, _hi_w, _co_w
             except Exception as e:
                 sec["wall_voxels_c2"] = {"skipped": "%s: %s" % (type(e).__name__, str(e)[:120])}
+            # (f) sparse label ids: the headline volume's cells renamed on the device to random ids below 2^31, then the census of
+            # the ids (np.unique on the device), the rank copy of the volume, and the same sweep over it (rows = ids present)
+            try:
+                ctx.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, keep=vol)
+                rng = np.random.default_rng(5)
+                top = (1 << 31) if dtype.itemsize == 4 else 65535
+                lut = np.unique(rng.integers(0, top, size=4 * (max_label + 1), dtype=np.uint64))
+                lut = rng.permutation(lut)[:max_label + 1].astype(np.uint32)
+                ctx.relabel(lut)                        # (the headline volume is not used after this)
+
+                def best_ms(f, reps=3):
+                    out_, best_ = None, 1e9
+                    for _ in range(reps):
+                        torch.cuda.synchronize()
+                        t1_ = time.perf_counter()
+                        out_ = f()
+                        torch.cuda.synchronize()
+                        best_ = min(best_, (time.perf_counter() - t1_) * 1e3)
+                    return best_, out_
+                census_ms, (top_id, ids_) = best_ms(ctx.label_census)
+                rank_ms, _ = best_ms(lambda: ctx.compact_labels())
+                ctx.bind_accumulators(None, None, 0)
+                ctx.set_option(_capi.OPT_TIMING_RING, 5)
+                for _ in range(5):
+                    ctx.extract(feats, ids_.size - 1)
+                ctx.adjacency_size()
+                ks = float(np.mean(ctx.timing_series()))
+                sec["sparse_ids"] = {"workload": "%s with its %d cells renamed to random ids up to %d (dense rows: %.1f GB)"
+                                                 % (cfg["name"], int(ids_.size), int(top_id), (top_id + 1) * 104 / 1e9),
+                                     "census_ms": round(census_ms, 4), "rank_copy_ms": round(rank_ms, 4), "kernel_ms": round(ks, 4),
+                                     "roofline_frac": round(bytes_read / (ks * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            except Exception as e:
+                sec["sparse_ids"] = {"skipped": "%s: %s" % (type(e).__name__, str(e)[:160])}
             out["secondary"] = sec
         if n == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_result
