@@ -2,19 +2,25 @@
 //
 // A STABLE least-significant-digit radix sort, hand-written (rounds 2-3 called hipCUB's): key = lo << bits | hi -- bits = what a
 // label of this volume takes, found by the count pass, so the sort runs over 2 x bits instead of 64 -- with the record index
-// as value; stable, so each pair's voxels stay in memory order; a gather then writes the records in that order.
-// One pass per 8-bit digit, three kernels a pass:
+// as value; stable, so each pair's voxels stay in memory order.  The key splits into as few digits of at most 10 bits as it
+// takes, all of one width (28 or 30 bits: three passes of 10; 32: four of 8).  Three kernels a pass:
 //   histogram  a workgroup counts the digits of its tile of 4096 keys in LDS and writes hist[digit][workgroup];
 //   scan       an exclusive scan over that table (digit-major) = where each workgroup's keys of each digit start;
 //   scatter    a wave owns 1024 consecutive keys of the tile and walks them 64 at a time, IN ORDER: a lane's rank among the
-//              lanes of its chunk that hold the same digit comes from eight ballots (one per digit bit), its position from
-//              the wave's running cursor of that digit in LDS -- no key ever overtakes an equal one.
+//              lanes of its chunk that hold the same digit comes from one ballot per digit bit, its position from the wave's
+//              running cursor of that digit in LDS -- no key ever overtakes an equal one.  The LAST pass writes the records
+//              themselves (pair from the key, coordinates through the index): no gather afterwards.
 // HBM-bound in principle (two reads + one write of 8 bytes a record per pass); the scatter's writes are runs of equal pairs.
 #include "ta_kernels.h"
 
 namespace ta {
 
 constexpr int RS_WAVES = 4, RS_PER_WAVE = 1024, RS_TILE = RS_WAVES * RS_PER_WAVE;      // keys per workgroup
+constexpr int RS_MAX_DIGIT_BITS = 10;
+
+// the passes a key of `key_bits` takes: as few as digits of at most 10 bits allow, all of the same width
+static int rs_passes(int key_bits) { return (key_bits + RS_MAX_DIGIT_BITS - 1) / RS_MAX_DIGIT_BITS; }
+static int rs_digit_bits(int key_bits) { const int p = rs_passes(key_bits); return (key_bits + p - 1) / p; }
 
 template <typename K>
 __global__ void __launch_bounds__(256) wall_sort_keys_kernel(const uint2* pairs, uint64_t n, K* keys, uint32_t* index, int bits) {
@@ -25,11 +31,12 @@ __global__ void __launch_bounds__(256) wall_sort_keys_kernel(const uint2* pairs,
     }
 }
 
-// The lanes of a chunk that hold the same digit as this lane (eight ballots, one per digit bit).
+// The lanes of a chunk that hold the same digit as this lane (one ballot per digit bit).
+template <int DB>
 __device__ __forceinline__ uint64_t digit_peers(const uint32_t d, const bool valid) {
     uint64_t peers = __builtin_amdgcn_ballot_w64(valid);
 #pragma unroll
-    for (int b = 0; b < 8; ++b) {
+    for (int b = 0; b < DB; ++b) {
         const bool bit = (d >> b) & 1u;
         const uint64_t m = __builtin_amdgcn_ballot_w64(valid && bit);
         peers &= bit ? m : ~m;
@@ -41,28 +48,40 @@ __device__ __forceinline__ uint64_t digit_peers(const uint32_t d, const bool val
 //  neighbours in memory -- which the CU serialises; counting by one lane per group of equal digits, through digit_peers, was
 //  built and is SLOWER -- C2 1.98 against 1.44 ms for the grouped fetch: three rounds of eight ballots a chunk and a
 //  read-modify-write the wave has to wait for cost more than the serialised atomics nobody waits for.)
-template <typename K>
+template <typename K, int DB>
 __global__ void __launch_bounds__(256) radix_hist_kernel(const K* keys, uint64_t n, int shift, uint32_t* hist, uint32_t nblocks) {
-    __shared__ uint32_t h[256];
-    h[threadIdx.x] = 0u;
+    constexpr int ND = 1 << DB;
+    __shared__ uint32_t h[ND];
+    for (int d = threadIdx.x; d < ND; d += 256) h[d] = 0u;
     __syncthreads();
     const uint64_t base = (uint64_t)blockIdx.x * RS_TILE;
 #pragma unroll 4
     for (int k = 0; k < RS_TILE / 256; ++k) {
         const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (ND - 1)], 1u);
     }
     __syncthreads();
-    hist[(uint64_t)threadIdx.x * nblocks + blockIdx.x] = h[threadIdx.x];
+    for (int d = threadIdx.x; d < ND; d += 256) hist[(uint64_t)d * nblocks + blockIdx.x] = h[d];
 }
 
-template <typename K>
+struct __attribute__((packed, aligned(4))) WallInt3 { int32_t x, y, z; };
+
+// LAST = the pass of the most significant digit: the records themselves go to their places (pair unpacked from the key, the
+// coordinates fetched through the index) instead of keys and indices that a gather would have to read again.
+// (Measured and dropped: the tile put in digit order in LDS first and written out a thread per local position, so that
+//  neighbouring lanes write neighbouring addresses -- C2 1.27 against 1.23 ms, C3 9.5 against 9.4: the scattered 4-byte
+//  stores are not what bounds a pass.  11-bit digits: 32 KB of cursors a workgroup and 2048 runs a tile, C3 12.9 against
+//  9.5 ms; tiles of 8192 keys: no change.)
+template <typename K, int DB, bool LAST>
 __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* keys_in, const uint32_t* vals_in, uint64_t n, int shift,
-                                                            const uint64_t* offs, uint32_t nblocks, K* keys_out, uint32_t* vals_out) {
-    __shared__ uint32_t cursor[RS_WAVES][256];          // first the digit counts of each wave, then its running cursors
+                                                            const uint64_t* offs, uint32_t nblocks, K* keys_out, uint32_t* vals_out,
+                                                            const WallInt3* coords, uint2* pairs_out, WallInt3* coords_out, int bits) {
+    constexpr int ND = 1 << DB;
+    __shared__ uint32_t cursor[RS_WAVES][ND];           // first the digit counts of each wave, then its running cursors
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    for (int d = tid; d < ND; d += 256)
 #pragma unroll
-    for (int k = 0; k < RS_WAVES; ++k) cursor[k][tid] = 0u;
+        for (int k = 0; k < RS_WAVES; ++k) cursor[k][d] = 0u;
     __syncthreads();
     const uint64_t wbase = (uint64_t)blockIdx.x * RS_TILE + (uint64_t)w * RS_PER_WAVE;
     const uint64_t lt = lane ? (~0ull >> (64 - lane)) : 0ull;                  // the lanes before this one
@@ -73,74 +92,87 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* keys_in, co
         const uint64_t i = wbase + (uint64_t)c * 64 + lane;
         key[c] = i < n ? keys_in[i] : (K)0;
         val[c] = i < n ? vals_in[i] : 0u;
-        if (i < n) atomicAdd(&cursor[w][(uint32_t)(key[c] >> shift) & 255u], 1u);
+        if (i < n) atomicAdd(&cursor[w][(uint32_t)(key[c] >> shift) & (ND - 1)], 1u);
     }
     __syncthreads();
-    {   // thread t owns digit t: where the workgroup's keys of that digit start, then wave by wave
-        uint32_t at = (uint32_t)offs[(uint64_t)tid * nblocks + blockIdx.x];
+    for (int d = tid; d < ND; d += 256) {   // a thread owns its digits: where the workgroup's keys of that digit start, then wave by wave
+        uint32_t at = (uint32_t)offs[(uint64_t)d * nblocks + blockIdx.x];
 #pragma unroll
-        for (int k = 0; k < RS_WAVES; ++k) { const uint32_t cnt = cursor[k][tid]; cursor[k][tid] = at; at += cnt; }
+        for (int k = 0; k < RS_WAVES; ++k) { const uint32_t cnt = cursor[k][d]; cursor[k][d] = at; at += cnt; }
     }
     __syncthreads();
+    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
 #pragma unroll
     for (int c = 0; c < RS_PER_WAVE / 64; ++c) {
         const bool valid = wbase + (uint64_t)c * 64 + lane < n;
-        const uint32_t d = (uint32_t)(key[c] >> shift) & 255u;
-        const uint64_t peers = digit_peers(d, valid);
+        const uint32_t d = (uint32_t)(key[c] >> shift) & (ND - 1);
+        const uint64_t peers = digit_peers<DB>(d, valid);
         const uint32_t rank = (uint32_t)__builtin_popcountll(peers & lt);
         uint32_t pos = 0u;
         if (valid) pos = cursor[w][d] + rank;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         if (valid && rank == 0u) cursor[w][d] += (uint32_t)__builtin_popcountll(peers);      // one lane per digit of the chunk
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        if (valid) { keys_out[pos] = key[c]; vals_out[pos] = val[c]; }
-    }
-}
-
-struct __attribute__((packed, aligned(4))) WallInt3 { int32_t x, y, z; };
-
-template <typename K>
-__global__ void __launch_bounds__(256) wall_gather_kernel(const K* keys, const uint32_t* index, const WallInt3* coords, uint64_t n,
-                                                          uint2* pairs_out, WallInt3* coords_out, int bits) {
-    const uint64_t mask = bits >= 64 ? ~0ull : ((1ull << bits) - 1);
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t k = (uint64_t)keys[i];
-        pairs_out[i] = make_uint2((uint32_t)(k >> bits), (uint32_t)(k & mask));
-        coords_out[i] = coords[index[i]];
+        if (valid) {
+            if (LAST) {
+                const uint64_t k = (uint64_t)key[c];
+                pairs_out[pos] = make_uint2((uint32_t)(k >> bits), (uint32_t)(k & mask));
+                coords_out[pos] = coords[val[c]];
+            } else {
+                keys_out[pos] = key[c];
+                vals_out[pos] = val[c];
+            }
+        }
     }
 }
 
 static uint64_t rs_blocks(uint64_t n) { return (n + RS_TILE - 1) / RS_TILE; }
 
-// hist u32[256][blocks] | offsets u64[256][blocks] | scan scratch
+// hist u32[digits][blocks] | offsets u64[digits][blocks] | scan scratch
 uint64_t wall_sort_temp_bytes(uint64_t n) {
-    const uint64_t cells = 256 * rs_blocks(n);
+    const uint64_t cells = (uint64_t)(1 << RS_MAX_DIGIT_BITS) * rs_blocks(n);
     return ((cells * 4 + 15) & ~15ull) + ((cells * 8 + 15) & ~15ull) + scan_u32_scratch_bytes(cells) + 64;
 }
 
-template <typename K>
-static hipError_t wall_group(hipStream_t s, const uint32_t* pairs, const int32_t* coords, uint64_t n, K* keys0, K* keys1,
-                             uint32_t* index0, uint32_t* index1, void* temp, int bits, uint32_t* pairs_out, int32_t* coords_out) {
+template <typename K, int DB>
+static hipError_t wall_group_db(hipStream_t s, const uint32_t* pairs, const int32_t* coords, uint64_t n, K* keys0, K* keys1,
+                                uint32_t* index0, uint32_t* index1, void* temp, int bits, uint32_t* pairs_out, int32_t* coords_out) {
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(wall_sort_keys_kernel<K>, dim3(blocks), dim3(256), 0, s, (const uint2*)pairs, n, keys0, index0, bits);
     const uint32_t nb = (uint32_t)rs_blocks(n);
-    const uint64_t cells = 256ull * nb;
+    const uint64_t cells = (uint64_t)(1 << DB) * nb;
     char* p = (char*)temp;
     uint32_t* hist = (uint32_t*)p; p += (cells * 4 + 15) & ~15ull;
     uint64_t* offs = (uint64_t*)p; p += (cells * 8 + 15) & ~15ull;
     K* kin = keys0; K* kout = keys1;
     uint32_t* vin = index0; uint32_t* vout = index1;
-    for (int shift = 0; shift < 2 * bits; shift += 8) {
-        hipLaunchKernelGGL(radix_hist_kernel<K>, dim3(nb), dim3(256), 0, s, kin, n, shift, hist, nb);
+    const int passes = rs_passes(2 * bits);
+    for (int pass = 0; pass < passes; ++pass) {
+        const int shift = pass * DB;
+        hipLaunchKernelGGL((radix_hist_kernel<K, DB>), dim3(nb), dim3(256), 0, s, kin, n, shift, hist, nb);
         launch_scan_u32_exclusive(s, hist, cells, p, offs);
-        hipLaunchKernelGGL(radix_scatter_kernel<K>, dim3(nb), dim3(256), 0, s, kin, vin, n, shift, offs, nb, kout, vout);
+        if (pass + 1 < passes)
+            hipLaunchKernelGGL((radix_scatter_kernel<K, DB, false>), dim3(nb), dim3(256), 0, s, kin, vin, n, shift, offs, nb, kout, vout,
+                               (const WallInt3*)nullptr, (uint2*)nullptr, (WallInt3*)nullptr, bits);
+        else
+            hipLaunchKernelGGL((radix_scatter_kernel<K, DB, true>), dim3(nb), dim3(256), 0, s, kin, vin, n, shift, offs, nb, kout, vout,
+                               (const WallInt3*)coords, (uint2*)pairs_out, (WallInt3*)coords_out, bits);
         K* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }
-    hipLaunchKernelGGL(wall_gather_kernel<K>, dim3(blocks), dim3(256), 0, s, kin, vin, (const WallInt3*)coords, n,
-                       (uint2*)pairs_out, (WallInt3*)coords_out, bits);
     return hipGetLastError();
+}
+
+template <typename K>
+static hipError_t wall_group(hipStream_t s, const uint32_t* pairs, const int32_t* coords, uint64_t n, K* keys0, K* keys1,
+                             uint32_t* index0, uint32_t* index1, void* temp, int bits, uint32_t* pairs_out, int32_t* coords_out) {
+    switch (rs_digit_bits(2 * bits)) {      // (2 .. 10: the widths a key of 2 .. 64 bits splits into; below 8: as 8)
+#define TA_RS_CASE(DB) case DB: return wall_group_db<K, DB>(s, pairs, coords, n, keys0, keys1, index0, index1, temp, bits, pairs_out, coords_out);
+        TA_RS_CASE(10) TA_RS_CASE(9) TA_RS_CASE(8)
+#undef TA_RS_CASE
+        default: return wall_group_db<K, 8>(s, pairs, coords, n, keys0, keys1, index0, index1, temp, bits, pairs_out, coords_out);
+    }
 }
 
 // pairs / coords: the records in memory order (n < 2^32).  keys[2], index[2]: double buffers of n entries (keys: 8 bytes an

@@ -94,6 +94,7 @@ struct ta_ctx {
     DevBuf census, census_ids, compact_vol;
     uint32_t census_max = 0;            // ids 0 .. census_max have a bit
     int64_t census_n = -1;              // ids present, -1 = no census
+    int64_t vol_max = -1;               // largest label of the resident buffer (halo included), -1 = not known
     bool compact = false;               // per-label ROWS are ranks 0 .. census_n - 1; every label VALUE handed out is an id
     std::vector<uint32_t> h_ids;        // rank -> id (host copy, compact mode)
 
@@ -151,8 +152,9 @@ uint32_t* maxlab_dev(ta_ctx* c) { return (uint32_t*)c->small.p + ta::NFLAGS + 1;
 // the volume the sweep reads: the rank copy in compact mode
 const void* sweep_vol(const ta_ctx* c) { return c->compact ? c->compact_vol.p : c->vol; }
 
-void drop_census(ta_ctx* c) {
+void drop_census(ta_ctx* c) {          // (whenever the voxels change)
     c->census_n = -1;
+    c->vol_max = -1;
     if (c->compact) { c->compact = false; c->extracted = c->checked = false; }
 }
 
@@ -937,6 +939,7 @@ TA_API int ta_volume_max_label(ta_ctx* c, uint32_t* max_label) {
     TA_HIP(hipStreamSynchronize(c->stream));
     TA_HIP(hipGetLastError());
     *max_label = v;
+    c->vol_max = v;
     return TA_OK;
 }
 
@@ -951,10 +954,14 @@ int build_census(ta_ctx* c, const uint32_t* ids, uint32_t n_ids) {
         for (uint32_t i = 1; i < n_ids; ++i)
             if (ids[i] <= ids[i - 1]) return fail(TA_EINVAL, "ids must be ascending and unique (ids[%u]=%u after %u)", i, ids[i], ids[i - 1]);
         top = n_ids ? ids[n_ids - 1] : 0u;
+    } else if (c->vol_max >= 0 && c->vol == c->owned_vol.p) {
+        top = (uint32_t)c->vol_max;                     // (ta_volume_max_label has been here, and only this library writes
+                                                        //  a volume it uploaded itself: no second pass)
     } else {
         ta::launch_max_label(c->stream, c->vol, c->itemsize, nvox, maxlab_dev(c));
         TA_HIP(hipMemcpyAsync(&top, maxlab_dev(c), sizeof(top), hipMemcpyDeviceToHost, c->stream));
         TA_HIP(hipStreamSynchronize(c->stream));
+        c->vol_max = top;
     }
     c->census_n = -1;
     if ((rc = c->census.reserve(ta::census_bytes(top))) != TA_OK) return rc;
