@@ -27,6 +27,17 @@ def movs(base, n):
     return " ".join('"v_mov_b32 %%%d, v%d\\n"' % (i, base + i) for i in range(n))
 
 
+def half_strips(base, quads, c):
+    """issue_half<Q>: an 8-byte strip (four voxels of a uint16 volume) into the first two registers of quad Q."""
+    o = ["    template <int Q> static __device__ __forceinline__ void issue_half(uint32_t voff, const void* sbase) {"]
+    for q in range(quads):
+        head = "if (Q == %d)" % q if q == 0 else ("else if (Q == %d)" % q if q < quads - 1 else "else")
+        o.append('        %s asm volatile("global_load_dwordx2 v[%d:%d], %%0, %%1" :: "v"(voff), "s"(sbase) : %s);'
+                 % (head, base + 4 * q, base + 4 * q + 1, c))
+    o.append("    }")
+    return o
+
+
 def table(base, adj):
     n = 21 if adj else 16
     c = clobbers(base, n)
@@ -38,6 +49,7 @@ def table(base, adj):
         o.append('        %s asm volatile("global_load_dwordx4 v[%d:%d], %%0, %%1" :: "v"(voff), "s"(sbase) : %s);'
                  % (head, base + 4 * q, base + 4 * q + 3, c))
     o.append("    }")
+    o += half_strips(base, quads, c)
     if adj:
         o.append("    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t voff, const void* sbase) {")
         for wide, four, reg in ((True, True, base + 20), (True, False, base + 12), (False, True, base + 20), (False, False, base + 12)):
@@ -80,6 +92,7 @@ def table_two_rows(base):
         o.append('        %s asm volatile("global_load_dwordx4 v[%d:%d], %%0, %%1" :: "v"(voff), "s"(sbase) : %s);'
                  % (head, base + 4 * q, base + 4 * q + 3, c))
     o.append("    }")
+    o += half_strips(base, 3, c)
     o.append("    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t voff, const void* sbase) {")
     o.append('        static_assert(RB == 2, "this budget holds two rows");')
     o.append('        if (sizeof(T) == 4) asm volatile("global_load_dword v%d, %%0, %%1" :: "v"(voff), "s"(sbase) : %s);' % (base + 12, c))

@@ -587,8 +587,10 @@ __device__ __forceinline__ void scan_load_strip(const bool EDGE, const T* row_c0
             dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
         } else {
             dst[0] = x.x & 0xffffu; dst[1] = x.x >> 16; dst[2] = x.y & 0xffffu; dst[3] = x.y >> 16;
-            dst[4 % VPL] = x.z & 0xffffu; dst[5 % VPL] = x.z >> 16;
-            dst[6 % VPL] = x.w & 0xffffu; dst[7 % VPL] = x.w >> 16;
+            if (VPL > 4) {           // (VPL = 4 of a uint16 volume: the lane's strip is the first half of what it loaded)
+                dst[4 % VPL] = x.z & 0xffffu; dst[5 % VPL] = x.z >> 16;
+                dst[6 % VPL] = x.w & 0xffffu; dst[7 % VPL] = x.w >> 16;
+            }
         }
     } else {
         const T* lane_p = reinterpret_cast<const T*>(reinterpret_cast<const char*>(row_c0) + lane_off);
@@ -653,8 +655,10 @@ __device__ __forceinline__ void unpack_strip(const u32x4& x, uint32_t (&dst)[VPL
         dst[0] = x.x; dst[1] = x.y; dst[2] = x.z; dst[3] = x.w;
     } else {
         dst[0] = x.x & 0xffffu; dst[1] = x.x >> 16; dst[2] = x.y & 0xffffu; dst[3] = x.y >> 16;
-        dst[4 % VPL] = x.z & 0xffffu; dst[5 % VPL] = x.z >> 16;
-        dst[6 % VPL] = x.w & 0xffffu; dst[7 % VPL] = x.w >> 16;
+        if (VPL > 4) {               // (VPL = 4 of a uint16 volume: 8-byte strips, loaded as the first half of 16 bytes)
+            dst[4 % VPL] = x.z & 0xffffu; dst[5 % VPL] = x.z >> 16;
+            dst[6 % VPL] = x.w & 0xffffu; dst[7 % VPL] = x.w >> 16;
+        }
     }
 }
 
@@ -683,7 +687,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #ifndef TA_FDRAIN
 #define TA_FDRAIN 128         // face records in the buffer from which the top-of-plane drain takes the full groups
 #endif
-    constexpr bool DRAIN_ALL = ADJ && TA_DRAIN_ALL && FCAP % 64 == 0 && RCAP % 64 == 0 && (TA_DRAIN_ALL_U16 || sizeof(T) == 4) && RB == 2 && !EDGE;
+    constexpr bool DRAIN_ALL = ADJ && TA_DRAIN_ALL && FCAP % 64 == 0 && RCAP % 64 == 0 && (TA_DRAIN_ALL_U16 || VPL == 4) && RB == 2 && !EDGE;
 
     const T* vol = reinterpret_cast<const T*>(A.vol);
     const int64_t n1 = A.n1, n2 = A.n2, plane = n1 * n2;
@@ -750,6 +754,16 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         next_row0 += plane_bytes;
 #endif
         using P = Pin<decltype(zone)::value>;
+        if constexpr (sizeof(T) == 2 && VPL == 4) {      // 8-byte strips: the first half of each landing quad
+            static_assert(RB == 2, "four uint16 voxels a lane: the two-row tiles");
+            P::template issue_half<0>(lane_off, row0);
+            P::template issue_half<1>(lane_off, row_in[1] ? row0 + rowbytes : row0);
+            if (ADJ) {
+                const bool up_there = has_up && (!PAD || b_wave0 < n1);
+                P::template issue_half<2>(lane_off, up_there ? row0 - rowbytes : row0);
+                P::template issue_voxel<T, RB>(left_off, has_left ? row0 - sizeof(T) : row0);
+            }
+        } else {
         P::template issue_strip<0>(lane_off, row0);
         P::template issue_strip<1>(lane_off, row_in[1] ? row0 + rowbytes : row0);
         if (RB > 2) {
@@ -762,6 +776,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             if (RB > 2) P::template issue_strip<4>(lane_off, up_there ? row0 - rowbytes : row0);
             else        P::template issue_strip<2>(lane_off, up_there ? row0 - rowbytes : row0);
             P::template issue_voxel<T, RB>(left_off, has_left ? row0 - sizeof(T) : row0);
+        }
         }
     };
     auto issue_plane = [&]() { issue_plane_to(std::integral_constant<int, (PINB ? PINB : TA_PIN_ADJ)>{}); };
@@ -1302,7 +1317,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_
 #endif
 template <typename T, int VPL, int RB, bool MOM2>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ2))) scan_two_rows_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
-    static_assert(RB == 2 && sizeof(T) == 4, "the 13-register landing zone holds two rows of a uint32 volume");
+    static_assert(RB == 2 && VPL == 4, "the 13-register landing zone holds two rows of four voxels a lane");
     scan_kernel_body<T, VPL, RB, true, MOM2, false, TA_PIN_ADJ2, TA_PERSIST != 0, (TA_PLANES_IN_FLIGHT == 2 ? TA_PIN_ADJ2B : 0)>(A, sp, wg0);
 }
 template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
@@ -1316,7 +1331,7 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_
 }
 template <typename T, int VPL, int RB, bool MOM2>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ2_PAD))) scan_pad2_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
-    static_assert(RB == 2 && sizeof(T) == 4, "the 13-register landing zone holds two rows of a uint32 volume");
+    static_assert(RB == 2 && VPL == 4, "the 13-register landing zone holds two rows of four voxels a lane");
     scan_kernel_body<T, VPL, RB, true, MOM2, true, TA_PIN_ADJ2_PAD>(A, sp, wg0);
 }
 template <typename T, int VPL, int RB, bool MOM2>
@@ -1336,13 +1351,13 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_star
     hipEvent_t in0 = ev_start, in1 = n_ed ? nullptr : ev_stop;              // interior launch
     hipEvent_t ed0 = n_in ? nullptr : ev_start, ed1 = ev_stop;              // edge launch
     if constexpr (ADJ) {
-        if constexpr (sizeof(T) == 4 && RB == 2) {
+        if constexpr (VPL == 4 && RB == 2) {
             const uint32_t grid = TA_PERSIST ? (n_in < (uint32_t)TA_PERSIST_WGS ? n_in : (uint32_t)TA_PERSIST_WGS) : n_in;
             if (n_in) hipExtLaunchKernelGGL((scan_two_rows_kernel<T, VPL, RB, MOM2>), dim3(grid), block, 0, s, in0, in1, 0, a, sp, 0u);
         } else {
             if (n_in) hipExtLaunchKernelGGL((scan_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
         }
-        if constexpr (sizeof(T) == 4 && RB == 2) {
+        if constexpr (VPL == 4 && RB == 2) {
             if (n_ed && sp.padded) hipExtLaunchKernelGGL((scan_pad2_kernel<T, VPL, RB, MOM2>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
         } else {
             if (n_ed && sp.padded) hipExtLaunchKernelGGL((scan_pad_kernel<T, VPL, RB, MOM2>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
@@ -1359,9 +1374,15 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_star
 // moments-only kernel is bound by the stream) and 2 x 256 with it (half the plane state: 95 VGPRs and 31 KB of LDS make five
 // waves per SIMD of a kernel that is bound by latency at four -- C4 1.13 -> 1.06 ms, tissue-filled 1.51 -> 1.40 ms at 48-plane tiles).
 constexpr int RB32_ADJ = 2, RB32_MOM = 4;
+// uint16 volumes with adjacency: 4 voxels a lane like the uint32 kernel (8-byte strips read as the first half of a 16-byte
+// load: the same 13-register landing zone, the same plane state, five waves per SIMD) or 8 (the pre-round-3 shape, 125 VGPRs)
+#ifndef TA_U16_VPL
+#define TA_U16_VPL 8
+#endif
+constexpr int VPL16_ADJ = TA_U16_VPL;
 
 uint64_t sweep_grid_size(const SweepArgs& a, int itemsize, bool adjacency) {
-    const ScanSplit sp = itemsize == 2 ? scan_split<8, 2>(a, 2) : (adjacency ? scan_split<4, RB32_ADJ>(a, 4) : scan_split<4, RB32_MOM>(a, 4));
+    const ScanSplit sp = itemsize == 2 ? (adjacency ? scan_split<VPL16_ADJ, 2>(a, 2) : scan_split<8, 2>(a, 2)) : (adjacency ? scan_split<4, RB32_ADJ>(a, 4) : scan_split<4, RB32_MOM>(a, 4));
     return (uint64_t)sp.tiles_c * sp.tiles_b * sp.nbands;
 }
 // measured on C4 / C5 (profiles/r03_ablations.txt, gpurun_out/r3_rb2_tp.txt): shorter tiles = more workgroups to balance over
@@ -1373,8 +1394,8 @@ int sweep_max_tile_planes() { return MAX_TILE_PLANES; }
 void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const bool adj = feature_mask & 16u, mom2 = feature_mask & 8u;
     if (itemsize == 2) {
-        if (adj && mom2)       launch_scan_tt<uint16_t, 8, 2, true, true>(s, a, ev_start, ev_stop);
-        else if (adj)          launch_scan_tt<uint16_t, 8, 2, true, false>(s, a, ev_start, ev_stop);
+        if (adj && mom2)       launch_scan_tt<uint16_t, VPL16_ADJ, 2, true, true>(s, a, ev_start, ev_stop);
+        else if (adj)          launch_scan_tt<uint16_t, VPL16_ADJ, 2, true, false>(s, a, ev_start, ev_stop);
         else if (mom2)         launch_scan_tt<uint16_t, 8, 2, false, true>(s, a, ev_start, ev_stop);
         else                   launch_scan_tt<uint16_t, 8, 2, false, false>(s, a, ev_start, ev_stop);
     } else {
