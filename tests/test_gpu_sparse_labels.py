@@ -47,6 +47,9 @@ CASES = [
     ("blocks_above_2_28", lambda: scatter_ids(random_blocks((11, 37, 70), 300, 3, np.uint32), 3, (1 << 29))),
     ("blocks_moderate", lambda: scatter_ids(random_blocks((17, 13, 29), 40, 4, np.uint32), 4, (1 << 20))),
     ("unaligned_rows", lambda: scatter_ids(voronoi((7, 9, 131), 20, 5, np.uint32), 5, (1 << 30))),
+    # rows that are not whole 16-byte vectors: the marking pass takes the volume as one run of pseudo-rows plus a remainder
+    ("odd_rows_many_ids", lambda: scatter_ids(random_blocks((33, 37, 131), 900, 6, np.uint32), 6, (1 << 31))),
+    ("odd_rows_long", lambda: scatter_ids(voronoi((5, 11, 2051), 60, 7, np.uint32), 7, (1 << 32) - 1)),
 ]
 
 
@@ -94,6 +97,10 @@ def test_dense_ids_are_left_dense_and_uint16_volumes_can_be_compacted_when_asked
     ids, want = oracle_by_rank(wide)
     gpu_ctx.set_volume(wide)
     assert_sparse_equal(extract_resident(gpu_ctx, wide.shape, sparse=True), ids, want)
+    odd = np.ascontiguousarray(wide[:, :, :123])                              # uint16 rows of 246 bytes
+    ids, want = oracle_by_rank(odd)
+    gpu_ctx.set_volume(odd)
+    assert_sparse_equal(extract_resident(gpu_ctx, odd.shape, sparse=True), ids, want)
 
 
 def test_the_host_accessors_answer_in_ids(gpu_ctx):

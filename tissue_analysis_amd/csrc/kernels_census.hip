@@ -288,23 +288,33 @@ void launch_census_mark(hipStream_t s, const void* vol, int itemsize, uint64_t n
                         uint32_t max_label) {
     uint8_t* touched = census_touched(scratch, max_label);
     if (n == 0) return;
-    if (row_len > 0 && ((uintptr_t)vol & 15) == 0 && (row_len * itemsize) % 16 == 0 && n % (uint64_t)row_len == 0) {
-        const uint32_t rowvec = (uint32_t)(row_len * itemsize / 16);
-        const uint64_t nrows = n / (uint64_t)row_len;
+    const int per = 16 / itemsize;
+    uint64_t done = 0;                                  // voxels the row kernel takes
+    if (((uintptr_t)vol & 15) == 0) {
+        // rows of whole 16-byte vectors: the strips walk down the real rows.  Otherwise the volume as one long run of
+        // 256-vector pseudo-rows: what is above a vector is then no neighbour of it, but the workgroup's LDS set -- the part
+        // that keeps the table out of the streaming loop -- works the same
+        const bool real_rows = row_len > 0 && (row_len * itemsize) % 16 == 0 && n % (uint64_t)row_len == 0;
+        const uint32_t rowvec = real_rows ? (uint32_t)(row_len * itemsize / 16) : 256u;
+        const uint64_t nrows = real_rows ? n / (uint64_t)row_len : (n / per) / 256u;
         const uint32_t strips = rowvec >= 256 ? (rowvec + 255) / 256 : 1;
         const uint32_t fold = rowvec >= 256 ? 1 : 256 / rowvec;
         const uint64_t chunks = (nrows + (uint64_t)CENSUS_ROWS_PER_BLOCK * fold - 1) / ((uint64_t)CENSUS_ROWS_PER_BLOCK * fold);
-        if (chunks * strips < (1ull << 31)) {
+        if (nrows && chunks * strips < (1ull << 31)) {
             const dim3 grid((unsigned)(chunks * strips));
             if (itemsize == 2) hipLaunchKernelGGL(census_mark_rows_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)vol, rowvec, nrows, strips, fold, (uint2*)census, touched);
             else               hipLaunchKernelGGL(census_mark_rows_kernel<uint32_t>, grid, dim3(256), 0, s, (const uint32_t*)vol, rowvec, nrows, strips, fold, (uint2*)census, touched);
-            return;
+            done = nrows * rowvec * (uint64_t)per;
         }
     }
-    const uint64_t nvec = ((uintptr_t)vol & 15) ? 0 : n / (16 / itemsize);
-    const unsigned blocks = stream_blocks(nvec ? nvec : n);
-    if (itemsize == 2) hipLaunchKernelGGL(census_mark_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)vol, n, nvec, (uint2*)census, touched);
-    else               hipLaunchKernelGGL(census_mark_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, (const uint32_t*)vol, n, nvec, (uint2*)census, touched);
+    if (done == n) return;
+    // what is left (less than a pseudo-row), or a volume that does not start on a 16-byte boundary: the flat kernel
+    const char* rest = (const char*)vol + done * itemsize;
+    const uint64_t m = n - done;
+    const uint64_t nvec = ((uintptr_t)rest & 15) ? 0 : m / per;
+    const unsigned blocks = stream_blocks(nvec ? nvec : m);
+    if (itemsize == 2) hipLaunchKernelGGL(census_mark_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)rest, m, nvec, (uint2*)census, touched);
+    else               hipLaunchKernelGGL(census_mark_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, (const uint32_t*)rest, m, nvec, (uint2*)census, touched);
 }
 
 void launch_census_from_ids(hipStream_t s, const uint32_t* ids_dev, uint64_t n, void* census, void* scratch, uint32_t max_label) {
