@@ -319,7 +319,8 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "peak_measured": round(peak_measured, 1), "frac_of_measured": round(achieved / peak_measured, 4),
-                         "kernel": ("scan_two_rows_kernel" if dtype.itemsize == 4 else "scan_kernel") if feats & _capi.F_ADJACENCY
+                         "kernel": (("scan_wide_kernel" if last_ctx().get_option(_capi.OPT_SWEEP_SHAPE_USED) else "scan_two_rows_kernel")
+                                    if dtype.itemsize == 4 else "scan_kernel") if feats & _capi.F_ADJACENCY
                                    else "scan_noadj_kernel",
                          "kernel_ms": round(sweep, 4), "kernel_launches_timed": len(sweep_ms),
                          "adjacency_collect_ms": round(float(np.mean(adj_ms)), 4),

@@ -70,6 +70,13 @@ extern "C" {
 #define TA_OPT_TIMING      4  /* HIP events per extraction: 0 none, 1 = begin / end of the sweep kernel (default; they ride on
                                * the kernel's own launch, hipExtLaunchKernelGGL: no packet of their own on the queue),
                                * 2 = also the step's begin / end (two event records, ~4 us of queue time each)      */
+#define TA_OPT_SWEEP_SHAPE 7  /* uint32 volumes with adjacency: the tile shape of the sweep.  1: a wave walks two rows of 512 columns
+                               * (eight voxels a lane, four waves per SIMD); 0: two rows of 256 (four voxels a lane, five waves).
+                               * Same results; 1 is ~5 % faster on tissue with background around it, 0 on a volume that is cells
+                               * everywhere, and on rows that are not whole 512-column tiles.  -1 (default): rows that are not take
+                               * 0; otherwise the first four sweeps of a volume take turns and the faster shape keeps the volume
+                               * (DESIGN.md §4.1). */
+#define TA_OPT_SWEEP_SHAPE_USED 8 /* read only: the shape the last sweep of this context ran with (0 where the shape does not apply) */
 #define TA_OPT_VOLUME_SLACK 6 /* bytes that are readable behind the volume adopted by ta_volume_set_device (reset to 0 by that
                                * call): with >= 16 the sweep uses 16-byte loads whatever the row length -- the strip that
                                * straddles the end of the last row reads up to 16 - itemsize bytes past the volume        */

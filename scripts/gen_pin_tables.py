@@ -19,6 +19,9 @@ TWO_ROW_TABLES = [82, 112, 96]  # adjacency, TWO rows per wave only: 13 register
                                 # 95: the second landing zone of the two-planes-in-flight experiment (behind 82's)
 
 
+WIDE_TABLES = [102, 116]        # adjacency, two rows of eight uint32 voxels a lane (25 registers); 116: the padded tiles
+
+
 def clobbers(base, n):
     return '"memory", ' + ", ".join('"v%d"' % (base + i) for i in range(n))
 
@@ -117,10 +120,36 @@ def table_two_rows(base):
     return "\n".join(o)
 
 
+def table_wide(base):
+    """Two rows of EIGHT uint32 voxels a lane: six quads (row 0 low / high half, row 1 low / high, the row above low / high)
+    and the voxel to the left: 25 registers."""
+    c = clobbers(base, 25)
+    o = ["template <> struct Pin<%d> {" % base,
+         "    template <int Q> static __device__ __forceinline__ void issue_strip(uint32_t voff, const void* sbase) {"]
+    for q in range(6):
+        head = "if (Q == %d)" % q if q == 0 else ("else if (Q == %d)" % q if q < 5 else "else")
+        o.append('        %s asm volatile("global_load_dwordx4 v[%d:%d], %%0, %%1" :: "v"(voff), "s"(sbase) : %s);'
+                 % (head, base + 4 * q, base + 4 * q + 3, c))
+    o.append("    }")
+    o.append("    template <typename T, int RB> static __device__ __forceinline__ void issue_voxel(uint32_t voff, const void* sbase) {")
+    o.append('        static_assert(sizeof(T) == 4 && RB == 2, "this layout holds two rows of a uint32 volume");')
+    o.append('        asm volatile("global_load_dword v%d, %%0, %%1" :: "v"(voff), "s"(sbase) : %s);' % (base + 24, c))
+    o.append("    }")
+    o.append("    static __device__ __forceinline__ void landed_wide(u32x4 (&q)[6], uint32_t& l) {")
+    o.append('        asm volatile("s_waitcnt vmcnt(0)\\n" %s' % movs(base, 25))
+    outs = ["\"=&v\"(q[%d].x), \"=&v\"(q[%d].y), \"=&v\"(q[%d].z), \"=&v\"(q[%d].w)" % (k, k, k, k) for k in range(6)]
+    o.append("                     : " + (",\n                       ").join(outs) + ', "=&v"(l)')
+    o.append('                     :: "memory");')
+    o.append("    }")
+    o.append("};")
+    return "\n".join(o)
+
+
 def render():
     head = ("// ta_pin_tables.inc -- GENERATED by scripts/gen_pin_tables.py (do not edit; `--check` compares): the hand-pinned landing\n"
             "// registers of the sweep kernels, one Pin<BASE> per VGPR budget, BASE = the first register above amdgpu_num_vgpr.\n")
-    return head + "\n".join([table(b, a) for b, a in TABLES] + [table_two_rows(b) for b in TWO_ROW_TABLES]) + "\n"
+    return head + "\n".join([table(b, a) for b, a in TABLES] + [table_two_rows(b) for b in TWO_ROW_TABLES]
+                            + [table_wide(b) for b in WIDE_TABLES]) + "\n"
 
 
 if __name__ == "__main__":

@@ -20,6 +20,7 @@ ap.add_argument("--dims", type=int, nargs=3, default=None)
 ap.add_argument("--cells", type=int, default=None)
 ap.add_argument("--no-ellipsoid", action="store_true")
 ap.add_argument("--no-check", action="store_true")
+ap.add_argument("--shape", type=int, default=None)      # TA_OPT_SWEEP_SHAPE (uint32 volumes with adjacency): 0 / 1
 args = ap.parse_args()
 c = synth.CONFIGS[args.config]
 dims = tuple(args.dims) if args.dims else c["dims"]
@@ -33,6 +34,8 @@ print("synth %.2fs dims=%s dtype=%s max_label=%d ellipsoid=%s" % (time.time() - 
                                                                   not args.no_ellipsoid), flush=True)
 ctx.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, keep=vol)
 ctx.set_option(_capi.OPT_TIMING, 2)          # also the step's begin / end events (adj / total columns)
+if args.shape is not None:
+    ctx.set_option(_capi.OPT_SWEEP_SHAPE, args.shape)
 ref = {}
 for feats in args.feat:
     for impl in args.impl:

@@ -11,5 +11,5 @@ rocprofv3 --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}_fetc
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/prof_${TAG}_write -- python3 $PARGS > $R/gpurun_out/prof_${TAG}_write.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS --output-format csv -d $R/gpurun_out/prof_${TAG}_sq -- python3 $PARGS > $R/gpurun_out/prof_${TAG}_sq.log 2>&1
 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS_ATOMIC SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --output-format csv -d $R/gpurun_out/prof_${TAG}_sq2 -- python3 $PARGS > $R/gpurun_out/prof_${TAG}_sq2.log 2>&1
-python3 $R/scripts/pmc_summary.py --kernel "scan_kernel|scan_two_rows_kernel|scan_noadj_kernel|init_kernel|pairs_collect|read_probe" $R/gpurun_out/prof_${TAG}_fetch $R/gpurun_out/prof_${TAG}_write $R/gpurun_out/prof_${TAG}_sq $R/gpurun_out/prof_${TAG}_sq2 > $R/gpurun_out/prof_${TAG}_pmc.txt 2>&1
+python3 $R/scripts/pmc_summary.py --kernel "scan_kernel|scan_wide_kernel|scan_two_rows_kernel|scan_noadj_kernel|init_kernel|pairs_collect|read_probe" $R/gpurun_out/prof_${TAG}_fetch $R/gpurun_out/prof_${TAG}_write $R/gpurun_out/prof_${TAG}_sq $R/gpurun_out/prof_${TAG}_sq2 > $R/gpurun_out/prof_${TAG}_pmc.txt 2>&1
 find $R/gpurun_out/prof_${TAG}_stats -name "*kernel_stats.csv" -exec cp {} $R/gpurun_out/prof_${TAG}_kernel_stats.csv \;

@@ -40,16 +40,23 @@ def test_c4_and_c3_full_size_against_the_c_oracle(capsys):
     vol, L = dev.synth_slab(ctx, dims, dtype, c["n_cells"], c["seed"])
     torch.cuda.synchronize()
     ctx.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, keep=vol)
+    ctx.set_option(_capi.OPT_SWEEP_SHAPE, 1)                        # the wide tiles of the uint32 sweep ...
     ctx.extract(_capi.F_ALL, L)
     got4 = fetch(ctx, L)
+    ctx.set_option(_capi.OPT_SWEEP_SHAPE, 0)                        # ... and the narrow ones
+    ctx.extract(_capi.F_ALL, L)
+    got4n = fetch(ctx, L)
+    ctx.set_option(_capi.OPT_SWEEP_SHAPE, -1)                       # left to measure: the second sweep of a volume is a narrow one
     c3 = _capi.feature_mask(synth.CONFIGS["C3"]["features"])
+    ctx.extract(c3, L)
     ctx.extract(c3, L)
     got3 = fetch(ctx, L)
     host = vol.cpu().numpy().view(dtype)
     ctx.close()
     del vol
     want = onepass_c.extract(host, max_label=L)
-    assert_same_accumulators(got4, want, "C4 1024^3 full feature set")
+    assert_same_accumulators(got4, want, "C4 1024^3 full feature set, wide tiles")
+    assert_same_accumulators(got4n, want, "C4 1024^3 full feature set, narrow tiles")
     for k in ("count", "bbox", "sum1", "pair_lo", "pair_hi", "pair_faces"):
         assert np.array_equal(got3[k], want[k]), "C3 " + k
     assert int((want["count"] > 0).sum()) > 20000 and want["pair_lo"].size > 100000
@@ -147,13 +154,18 @@ def test_c4_tissue_filled_full_size_against_the_c_oracle(capsys):
     vol, L = dev.synth_slab(ctx, dims, dtype, c["n_cells"], c["seed"], ellipsoid=False)
     torch.cuda.synchronize()
     ctx.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, keep=vol)
+    ctx.set_option(_capi.OPT_SWEEP_SHAPE, 1)                        # both tile shapes of the uint32 sweep at this size
     ctx.extract(_capi.F_ALL, L)
     got = fetch(ctx, L)
+    ctx.set_option(_capi.OPT_SWEEP_SHAPE, 0)
+    ctx.extract(_capi.F_ALL, L)
+    got_narrow = fetch(ctx, L)
     host = vol.cpu().numpy().view(dtype)
     ctx.close()
     del vol
     want = onepass_c.extract(host, max_label=L)
-    assert_same_accumulators(got, want, "tissue-filled C4 1024^3 full feature set")
+    assert_same_accumulators(got, want, "tissue-filled C4 1024^3 full feature set, wide tiles")
+    assert_same_accumulators(got_narrow, want, "tissue-filled C4 1024^3 full feature set, narrow tiles")
     present = int((want["count"] > 0).sum())
     assert present > 50000 and want["count"][1] == 0                # all cells, no background
     # the caller's side at this size: the tissue graph from these arrays (host time only, the sweep is done)

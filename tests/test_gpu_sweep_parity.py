@@ -234,3 +234,46 @@ def test_adopted_buffers_with_unaligned_rows(shape, dtype, slack):
                 assert np.array_equal(lo, want["pair_lo"]) and np.array_equal(hi, want["pair_hi"]) and np.array_equal(faces, want["pair_faces"])
     finally:
         ctx.close()
+
+
+SHAPE_CASES = [
+    ("voronoi_1024_wide", lambda: voronoi((20, 24, 1024), 60, 21, np.uint32)),
+    ("left_boundary_512", lambda: _half_and_half((26, 32, 512), np.uint32)),
+    ("flat_wall_512", lambda: _flat_wall((5, 16, 512), np.uint32)),
+    ("ragged_520", lambda: voronoi((9, 20, 520), 40, 22, np.uint32)),          # forced wide: a partial tile column
+    ("short_rows_300", lambda: voronoi((7, 13, 300), 20, 23, np.uint32)),       # forced wide: no whole tile at all
+    ("dense_blocks_1024", lambda: random_blocks((6, 16, 1024), 3000, 24, np.uint32)),
+]
+
+
+@pytest.mark.parametrize("shape", [0, 1], ids=["narrow", "wide"])
+@pytest.mark.parametrize("name,make", SHAPE_CASES, ids=[c[0] for c in SHAPE_CASES])
+def test_both_tile_shapes_of_the_uint32_sweep_match_the_oracle(gpu_ctx, name, make, shape):
+    """TA_OPT_SWEEP_SHAPE: two rows of 256 columns a wave (0) or of 512 (1) -- the same integers either way, also where the
+    wide tiles are forced onto rows they would not be chosen for."""
+    vol = make()
+    want = onepass_c.extract(vol)
+    gpu_ctx.set_option(_capi.OPT_SWEEP_SHAPE, shape)
+    try:
+        for tp in (0, 5):
+            for feats in (_capi.F_ALL, 0x17):
+                got = run(gpu_ctx, vol, 0, feats, tile_planes=tp)
+                w = dict(want, sum2=np.zeros_like(want["sum2"])) if not feats & _capi.F_MOMENT2 else want
+                assert_same_accumulators(got, w, "%s shape=%d tp=%d feats=0x%x" % (name, shape, tp, feats))
+    finally:
+        gpu_ctx.set_option(_capi.OPT_SWEEP_SHAPE, -1)
+        gpu_ctx.set_option(_capi.OPT_TILE_PLANES, 0)
+
+
+def test_the_measured_choice_of_the_shape_never_changes_the_result(gpu_ctx):
+    """Left to itself a context lets the first four sweeps of a volume take turns between the shapes and keeps the faster one:
+    eight sweeps of one resident volume, every one equal to the oracle."""
+    vol = voronoi((24, 32, 1024), 80, 25, np.uint32)
+    want = onepass_c.extract(vol)
+    gpu_ctx.set_volume(vol)
+    for k in range(8):
+        gpu_ctx.extract(_capi.F_ALL, int(vol.max()))
+        count, bbox, s1, s2 = gpu_ctx.labels()
+        lo, hi, f = gpu_ctx.adjacency()
+        got = dict(max_label=int(vol.max()), count=count, bbox=bbox, sum1=s1, sum2=s2, pair_lo=lo, pair_hi=hi, pair_faces=f)
+        assert_same_accumulators(got, want, "sweep %d" % k)

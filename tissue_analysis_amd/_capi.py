@@ -20,7 +20,7 @@ ADJ_LOCAL, ADJ_MERGED, ADJ_PARTIAL = 0, 1, 2
 ABI_VERSION = 4          # TA_ABI_VERSION of include/tissue_scan.h this binding was written against
 FEATURES = dict(VOLUME=F_VOLUME, BBOX=F_BBOX, MOMENT1=F_MOMENT1, MOMENT2=F_MOMENT2,
                 ADJACENCY=F_ADJACENCY)
-OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS, OPT_TIMING, OPT_TIMING_RING, OPT_VOLUME_SLACK = 1, 2, 3, 4, 5, 6
+OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS, OPT_TIMING, OPT_TIMING_RING, OPT_VOLUME_SLACK, OPT_SWEEP_SHAPE, OPT_SWEEP_SHAPE_USED = 1, 2, 3, 4, 5, 6, 7, 8
 STREAM_LEGACY_DEFAULT = 1          # TA_STREAM_LEGACY_DEFAULT of include/tissue_scan.h
 
 # every symbol include/tissue_scan.h declares

@@ -52,7 +52,7 @@ def _check_pinned(hipcc, verbose=False):
     subprocess.check_call(cmd, cwd=OBJDIR)
     bases = {}
     for line in open(os.path.join(CSRC, "kernels_scan.hip")):
-        m = re.match(r"#define TA_PIN_(ADJ2_PAD|ADJ_PAD|MOM_PAD|ADJ2|ADJ|MOM) (\d+)", line)
+        m = re.match(r"#define TA_PIN_(ADJ8_PAD|ADJ8|ADJ2_PAD|ADJ_PAD|MOM_PAD|ADJ2|ADJ|MOM) (\d+)", line)
         if m:
             bases[m.group(1)] = int(m.group(2))
     reg = re.compile(r"\bv(\d+)\b|\bv\[(\d+):(\d+)\]")
@@ -70,9 +70,13 @@ def _check_pinned(hipcc, verbose=False):
                 continue
             if in_asm or not t or t[0] in ";.":
                 continue
-            if re.search(r"scan_(noadj_)?kernelI\w*Lb1EEEvNS_9SweepArgs", func):
+            if re.search(r"scan_(noadj_|wide_)?kernelI\w*Lb1EEEvNS_9SweepArgs", func):
                 continue              # edge kernels issue no hand-pinned loads: any register is theirs
-            if "scan_noadj_pad_kernel" in func:
+            if "scan_wide_pad_kernel" in func:
+                ranges = [bases["ADJ8_PAD"], bases["ADJ8_PAD"] + 4]      # (25 registers: two overlapping windows of 21)
+            elif "scan_wide_kernel" in func:
+                ranges = [bases["ADJ8"], bases["ADJ8"] + 4]
+            elif "scan_noadj_pad_kernel" in func:
                 ranges = [bases["MOM_PAD"]]
             elif "scan_pad2_kernel" in func:
                 ranges = [bases["ADJ2_PAD"]]
@@ -91,7 +95,7 @@ def _check_pinned(hipcc, verbose=False):
                 if any(hi >= b and lo < b + 21 for b in ranges):      # (21 pinned with adjacency, 16 without: the wider check is safe)
                     bad.append("%s:%d: %s" % (func, ln, t))
                     break
-    if bad or len(bases) != 6:
+    if bad or len(bases) != 8:
         raise RuntimeError("compiler-allocated VGPRs reach the hand-pinned registers in kernels_scan.hip:\n  %s"
                            % "\n  ".join(bad[:10]))
 

@@ -639,6 +639,11 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 // the PADDED kernels (partial tiles of a volume whose rows are 16-byte aligned: interior-style loads, edge-style
 // semantics) carry more state: with adjacency 116 + 21 = 137 (three waves per SIMD), without 80 + 16 = 96 (five, like the
 // interior kernel)
+// two rows of EIGHT uint32 voxels a lane (TA_U32_SHAPE = 1): 25 pinned registers (an even base: 16-byte loads want even register pairs), 102 + 25 = 127: four waves per SIMD
+#define TA_PIN_ADJ8 102
+#define TA_CAP_ADJ8 98
+#define TA_PIN_ADJ8_PAD 116
+#define TA_CAP_ADJ8_PAD 112
 #define TA_PIN_ADJ_PAD 120
 #define TA_PIN_MOM_PAD 80
 #define TA_CAP_ADJ_PAD 116
@@ -682,7 +687,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #define TA_DRAIN_ALL 1
 #endif
 #ifndef TA_DRAIN_ALL_U16
-#define TA_DRAIN_ALL_U16 0    // the full tiles of uint16 volumes too (their kernel sits at 125 VGPRs: see the build's register check)
+#define TA_DRAIN_ALL_U16 1    // the full tiles of uint16 volumes too (their kernel sits at 125 VGPRs: see the build's register check)
 #endif
 #ifndef TA_FDRAIN
 #define TA_FDRAIN 128         // face records in the buffer from which the top-of-plane drain takes the full groups
@@ -754,7 +759,19 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         next_row0 += plane_bytes;
 #endif
         using P = Pin<decltype(zone)::value>;
-        if constexpr (sizeof(T) == 2 && VPL == 4) {      // 8-byte strips: the first half of each landing quad
+        if constexpr (sizeof(T) == 4 && VPL == 8) {      // 32-byte strips: two quads a row, two rows, two quads the row above
+            static_assert(RB == 2 && ADJ, "eight uint32 voxels a lane: two rows a wave, the 25-register landing zone");
+            const char* row1 = row_in[1] ? row0 + rowbytes : row0;
+            P::template issue_strip<0>(lane_off, row0);
+            P::template issue_strip<1>(lane_off, row0 + 16);
+            P::template issue_strip<2>(lane_off, row1);
+            P::template issue_strip<3>(lane_off, row1 + 16);
+            const bool up_there = has_up && (!PAD || b_wave0 < n1);
+            const char* upr = up_there ? row0 - rowbytes : row0;
+            P::template issue_strip<4>(lane_off, upr);
+            P::template issue_strip<5>(lane_off, upr + 16);
+            P::template issue_voxel<T, RB>(left_off, has_left ? row0 - sizeof(T) : row0);
+        } else if constexpr (sizeof(T) == 2 && VPL == 4) {      // 8-byte strips: the first half of each landing quad
             static_assert(RB == 2, "four uint16 voxels a lane: the two-row tiles");
             P::template issue_half<0>(lane_off, row0);
             P::template issue_half<1>(lane_off, row_in[1] ? row0 + rowbytes : row0);
@@ -910,6 +927,37 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     // ---- prologue: the plane before the tile (another tile's, or the slab's halo plane) only gives faces
     uint32_t nxt[RB][VPL], nxt_up[VPL], nxt_leftv = INVALID_LABEL;           // edge tiles: the plane in flight, unpacked
     u32x4 nraw[RB], nup_raw;                                                  // interior tiles: the plane just read back
+    u32x4 nraw_hi[RB], nup_hi;                                                // (eight uint32 voxels a lane: their second halves)
+    constexpr bool WIDE8 = sizeof(T) == 4 && VPL == 8;
+    auto land = [&](auto zone, auto keep4) {               // the plane in flight -> nraw / nup_raw / nxt_leftv
+        using P = Pin<decltype(zone)::value>;
+        if constexpr (WIDE8) {
+            u32x4 t[6];
+            P::landed_wide(t, nxt_leftv);
+            nraw[0] = t[0]; nraw_hi[0] = t[1]; nraw[RB - 1] = t[2]; nraw_hi[RB - 1] = t[3]; nup_raw = t[4]; nup_hi = t[5];
+        } else if constexpr (decltype(keep4)::value) {
+            P::template landed_keep4<RB>(nraw, nup_raw, nxt_leftv);
+        } else {
+            P::template landed<RB>(nraw, nup_raw, nxt_leftv);
+        }
+    };
+    auto unpack_row = [&](const int r, uint32_t (&dst)[VPL]) {
+        if constexpr (WIDE8) {
+            dst[0] = nraw[r].x; dst[1] = nraw[r].y; dst[2] = nraw[r].z; dst[3] = nraw[r].w;
+            dst[4 % VPL] = nraw_hi[r].x; dst[5 % VPL] = nraw_hi[r].y; dst[6 % VPL] = nraw_hi[r].z; dst[7 % VPL] = nraw_hi[r].w;
+        } else {
+            unpack_strip<T, VPL>(nraw[r], dst);
+        }
+    };
+    auto unpack_up = [&](uint32_t (&dst)[VPL]) {
+        if constexpr (WIDE8) {
+            dst[0] = nup_raw.x; dst[1] = nup_raw.y; dst[2] = nup_raw.z; dst[3] = nup_raw.w;
+            dst[4 % VPL] = nup_hi.x; dst[5 % VPL] = nup_hi.y; dst[6 % VPL] = nup_hi.z; dst[7 % VPL] = nup_hi.w;
+        } else {
+            unpack_strip<T, VPL>(nup_raw, dst);
+        }
+    };
+    using ZoneA = std::integral_constant<int, (PINB ? PINB : TA_PIN_ADJ)>;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) { up[j] = INVALID_LABEL; nxt_up[j] = INVALID_LABEL; }
     if constexpr (PINB == 0) {
@@ -918,9 +966,9 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     } else {
         if (has_prev) {
             issue_plane();
-            Pin<PINB>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+            land(ZoneA{}, std::false_type{});
 #pragma unroll
-            for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], cur[r]);
+            for (int r = 0; r < RB; ++r) unpack_row(r, cur[r]);
             if constexpr (PAD) {
                 uint32_t dump_up[VPL], dump_l = 0u;
 #pragma unroll
@@ -953,8 +1001,8 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         } else {
             uint32_t nw[RB][VPL], nup[VPL];
 #pragma unroll
-            for (int r = 0; r < RB; ++r) unpack_strip<T, VPL>(nraw[r], nw[r]);
-            if (ADJ) unpack_strip<T, VPL>(nup_raw, nup);
+            for (int r = 0; r < RB; ++r) unpack_row(r, nw[r]);
+            if (ADJ) unpack_up(nup);
             pad_plane(nw, nup, nxt_leftv);
 #pragma unroll
             for (int r = 0; r < RB; ++r)
@@ -1076,14 +1124,14 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         if (p_lo + 1 < p_hi) issue_plane_to(ZB{});
         for (int32_t p = p_lo; p < p_hi; p += 2) {
             top_drains();
-            if (p + 1 < p_hi) Pin<PINB>::template landed_keep4<RB>(nraw, nup_raw, nxt_leftv);
-            else Pin<PINB>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+            if (p + 1 < p_hi) land(ZA{}, std::true_type{});
+            else land(ZA{}, std::false_type{});
             if (p + 2 < p_hi) issue_plane_to(ZA{});
             process_plane(p);
             if (p + 1 < p_hi) {
                 top_drains();
-                if (p + 2 < p_hi) Pin<PINB2>::template landed_keep4<RB>(nraw, nup_raw, nxt_leftv);
-                else Pin<PINB2>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+                if (p + 2 < p_hi) land(ZB{}, std::true_type{});
+                else land(ZB{}, std::false_type{});
                 if (p + 3 < p_hi) issue_plane_to(ZB{});
                 process_plane(p + 1);
             }
@@ -1103,7 +1151,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #ifdef TA_STAMPS
                 const uint64_t t4 = TA_T();
 #endif
-                Pin<PINB ? PINB : TA_PIN_ADJ>::template landed<RB>(nraw, nup_raw, nxt_leftv);
+                land(ZoneA{}, std::false_type{});
 #ifdef TA_STAMPS
                 tk_land += TA_T() - t4;
 #endif
@@ -1329,6 +1377,14 @@ template <typename T, int VPL, int RB, bool MOM2>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ_PAD))) scan_pad_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
     scan_kernel_body<T, VPL, RB, true, MOM2, true, TA_PIN_ADJ_PAD>(A, sp, wg0);
 }
+template <typename T, int VPL, int RB, bool MOM2, bool EDGE>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ8))) scan_wide_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+    scan_kernel_body<T, VPL, RB, true, MOM2, EDGE, EDGE ? 0 : TA_PIN_ADJ8>(A, sp, wg0);
+}
+template <typename T, int VPL, int RB, bool MOM2>
+__global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ8_PAD))) scan_wide_pad_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
+    scan_kernel_body<T, VPL, RB, true, MOM2, true, TA_PIN_ADJ8_PAD>(A, sp, wg0);
+}
 template <typename T, int VPL, int RB, bool MOM2>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ2_PAD))) scan_pad2_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
     static_assert(RB == 2 && VPL == 4, "the 13-register landing zone holds two rows of four voxels a lane");
@@ -1350,7 +1406,11 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_star
     const dim3 block(WAVES * 64);
     hipEvent_t in0 = ev_start, in1 = n_ed ? nullptr : ev_stop;              // interior launch
     hipEvent_t ed0 = n_in ? nullptr : ev_start, ed1 = ev_stop;              // edge launch
-    if constexpr (ADJ) {
+    if constexpr (ADJ && sizeof(T) == 4 && VPL == 8) {
+        if (n_in) hipExtLaunchKernelGGL((scan_wide_kernel<T, VPL, RB, MOM2, false>), dim3(n_in), block, 0, s, in0, in1, 0, a, sp, 0u);
+        if (n_ed && sp.padded) hipExtLaunchKernelGGL((scan_wide_pad_kernel<T, VPL, RB, MOM2>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
+        if (n_ed && !sp.padded) hipExtLaunchKernelGGL((scan_wide_kernel<T, VPL, RB, MOM2, true>), dim3(n_ed), block, 0, s, ed0, ed1, 0, a, sp, n_in);
+    } else if constexpr (ADJ) {
         if constexpr (VPL == 4 && RB == 2) {
             const uint32_t grid = TA_PERSIST ? (n_in < (uint32_t)TA_PERSIST_WGS ? n_in : (uint32_t)TA_PERSIST_WGS) : n_in;
             if (n_in) hipExtLaunchKernelGGL((scan_two_rows_kernel<T, VPL, RB, MOM2>), dim3(grid), block, 0, s, in0, in1, 0, a, sp, 0u);
@@ -1373,6 +1433,9 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_star
 // Rows per wave: uint16 volumes 2 x 512 columns; uint32 volumes 4 x 256 without adjacency (four rows in flight per wave: the
 // moments-only kernel is bound by the stream) and 2 x 256 with it (half the plane state: 95 VGPRs and 31 KB of LDS make five
 // waves per SIMD of a kernel that is bound by latency at four -- C4 1.13 -> 1.06 ms, tissue-filled 1.51 -> 1.40 ms at 48-plane tiles).
+// uint32 volumes with adjacency: TA_U32_SHAPE 0 = two rows of 256 columns a wave (four voxels a lane, the 13-register landing
+// zone, 95 VGPRs, five waves per SIMD); 1 = two rows of 512 columns (eight voxels a lane through two 16-byte loads a row, a
+// 25-register zone, 128 VGPRs, four waves): the shape of the uint16 kernel, twice the voxels per plane step of a wave
 constexpr int RB32_ADJ = 2, RB32_MOM = 4;
 // uint16 volumes with adjacency: 4 voxels a lane like the uint32 kernel (8-byte strips read as the first half of a 16-byte
 // load: the same 13-register landing zone, the same plane state, five waves per SIMD) or 8 (the pre-round-3 shape, 125 VGPRs)
@@ -1382,13 +1445,15 @@ constexpr int RB32_ADJ = 2, RB32_MOM = 4;
 constexpr int VPL16_ADJ = TA_U16_VPL;
 
 uint64_t sweep_grid_size(const SweepArgs& a, int itemsize, bool adjacency) {
-    const ScanSplit sp = itemsize == 2 ? (adjacency ? scan_split<VPL16_ADJ, 2>(a, 2) : scan_split<8, 2>(a, 2)) : (adjacency ? scan_split<4, RB32_ADJ>(a, 4) : scan_split<4, RB32_MOM>(a, 4));
+    const ScanSplit sp = itemsize == 2 ? (adjacency ? scan_split<VPL16_ADJ, 2>(a, 2) : scan_split<8, 2>(a, 2)) : (adjacency ? (a.shape ? scan_split<8, RB32_ADJ>(a, 4) : scan_split<4, RB32_ADJ>(a, 4)) : scan_split<4, RB32_MOM>(a, 4));
     return (uint64_t)sp.tiles_c * sp.tiles_b * sp.nbands;
 }
 // measured on C4 / C5 (profiles/r03_ablations.txt, gpurun_out/r3_rb2_tp.txt): shorter tiles = more workgroups to balance over
 // the CUs against more table inits / flushes.  The two-row tiles of uint32 volumes with adjacency cover half the rows, so
 // they walk twice the planes for the same voxels per workgroup (40 and 48 measure the same, 24 is 3 % slower, 64 1 %).
-int sweep_default_tile_planes(bool adjacency, int itemsize) { return adjacency ? (itemsize == 4 ? 48 : 24) : 16; }
+// (The wide uint32 tiles -- 8 rows x 512 columns -- hold twice the voxels a plane: 32 planes measure best on C4 and C5, and at
+//  48 the tissue-filled volume overflows the workgroup tables.)
+int sweep_default_tile_planes(bool adjacency, int itemsize, int shape) { return adjacency ? (itemsize == 4 ? (shape ? 32 : 48) : 24) : 16; }
 int sweep_max_tile_planes() { return MAX_TILE_PLANES; }
 
 void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask, hipEvent_t ev_start, hipEvent_t ev_stop) {
@@ -1399,8 +1464,8 @@ void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t featu
         else if (mom2)         launch_scan_tt<uint16_t, 8, 2, false, true>(s, a, ev_start, ev_stop);
         else                   launch_scan_tt<uint16_t, 8, 2, false, false>(s, a, ev_start, ev_stop);
     } else {
-        if (adj && mom2)       launch_scan_tt<uint32_t, 4, RB32_ADJ, true, true>(s, a, ev_start, ev_stop);
-        else if (adj)          launch_scan_tt<uint32_t, 4, RB32_ADJ, true, false>(s, a, ev_start, ev_stop);
+        if (adj && mom2)       { if (a.shape) launch_scan_tt<uint32_t, 8, RB32_ADJ, true, true>(s, a, ev_start, ev_stop); else launch_scan_tt<uint32_t, 4, RB32_ADJ, true, true>(s, a, ev_start, ev_stop); }
+        else if (adj)          { if (a.shape) launch_scan_tt<uint32_t, 8, RB32_ADJ, true, false>(s, a, ev_start, ev_stop); else launch_scan_tt<uint32_t, 4, RB32_ADJ, true, false>(s, a, ev_start, ev_stop); }
         else if (mom2)         launch_scan_tt<uint32_t, 4, RB32_MOM, false, true>(s, a, ev_start, ev_stop);
         else                   launch_scan_tt<uint32_t, 4, RB32_MOM, false, false>(s, a, ev_start, ev_stop);
     }

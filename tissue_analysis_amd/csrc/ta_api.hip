@@ -128,6 +128,16 @@ struct ta_ctx {
     // options / state
     int impl = 0;
     int tile_planes = 0;
+    // the tile shape of the sweep of a uint32 volume with adjacency (kernels_scan.hip): both give the same results; which one
+    // is faster depends on the tissue (background around it: the wide one; cells everywhere: the narrow one), so the first four
+    // sweeps of a volume take turns (wide, narrow, wide, narrow) between two events each, and the faster shape keeps the volume
+    int opt_shape = -1;                                 // TA_OPT_SWEEP_SHAPE: -1 = measure, 0 / 1 = as told
+    int shape_pick = -1;                                // measured choice for this volume, -1 = not yet
+    int last_shape = 0;                                 // TA_OPT_SWEEP_SHAPE_USED: the shape of the last sweep
+    int tune_launched = 0;                              // measuring sweeps launched (0 .. 4)
+    hipEvent_t tune_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    bool tune_done[4] = {false, false, false, false};
+    float tune_ms[4] = {0.f, 0.f, 0.f, 0.f};
     int64_t volume_slack = 0;                           // TA_OPT_VOLUME_SLACK: bytes readable behind an adopted volume
     int auto_tile_shift = 0;                            // automatic tile height halved this many times (table spills seen)
     uint64_t last_grid = 0;                             // workgroups of the last sweep
@@ -155,6 +165,9 @@ const void* sweep_vol(const ta_ctx* c) { return c->compact ? c->compact_vol.p : 
 void drop_census(ta_ctx* c) {          // (whenever the voxels change)
     c->census_n = -1;
     c->vol_max = -1;
+    c->shape_pick = -1;
+    c->tune_launched = 0;
+    for (bool& d : c->tune_done) d = false;
     if (c->compact) { c->compact = false; c->extracted = c->checked = false; }
 }
 
@@ -191,6 +204,35 @@ int auto_pair_log2(uint32_t max_label) {
     return l;
 }
 
+// The sweep shape of this launch; *tune = the measuring slot (0 .. 3) whose events bracket it, or -1.
+int sweep_shape(ta_ctx* c, bool adjacency, int* tune) {
+    *tune = -1;
+    if (c->itemsize != 4 || !adjacency) return 0;
+    if (c->opt_shape >= 0) return c->opt_shape;
+    // the wide tiles want whole 512-column tiles: the partial ones run a kernel with three waves per SIMD (1000^3: 1.24
+    // against 1.05 ms), and a volume narrower than a tile has nothing else
+    if (c->mdims[2] % 512 != 0) return 0;
+    if (c->shape_pick >= 0) return c->shape_pick;
+    bool all = c->tune_launched == 4;
+    for (int k = 0; k < c->tune_launched; ++k) {
+        if (!c->tune_done[k]) {
+            if (hipEventQuery(c->tune_ev[2 * k + 1]) == hipSuccess &&
+                hipEventElapsedTime(&c->tune_ms[k], c->tune_ev[2 * k], c->tune_ev[2 * k + 1]) == hipSuccess) c->tune_done[k] = true;
+            else (void)hipGetLastError();             // (not ready: asked again by the next sweep)
+        }
+        all = all && c->tune_done[k];
+    }
+    if (all) {
+        c->shape_pick = std::min(c->tune_ms[0], c->tune_ms[2]) <= std::min(c->tune_ms[1], c->tune_ms[3]) ? 1 : 0;
+        return c->shape_pick;
+    }
+    if (c->tune_launched < 4 && c->tune_ev[7]) {
+        *tune = c->tune_launched++;
+        return (*tune & 1) ^ 1;                       // wide, narrow, wide, narrow
+    }
+    return 1;                                         // (measured sweeps still in flight)
+}
+
 // One full extraction pass on the stream (no host sync).
 int run_extract(ta_ctx* c) {
     const uint64_t nlabels = (uint64_t)c->max_label + 1;
@@ -199,7 +241,10 @@ int run_extract(ta_ctx* c) {
     a.n0 = c->mdims[0]; a.n1 = c->mdims[1]; a.n2 = c->mdims[2];
     a.a_origin = c->a_origin;
     a.first_owned = c->first_owned;
-    a.tile_planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY, c->itemsize);
+    int tune = -1;
+    a.shape = sweep_shape(c, c->feature_mask & TA_F_ADJACENCY, &tune);
+    c->last_shape = a.shape;
+    a.tile_planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY, c->itemsize, a.shape);
     if (c->tile_planes <= 0) {
         // automatic: small volumes get shorter tiles until the launch has >= 2048 workgroups (8 per CU)
         while (a.tile_planes > 8 && ta::sweep_grid_size(a, c->itemsize, c->feature_mask & TA_F_ADJACENCY) < 2048) a.tile_planes /= 2;
@@ -249,6 +294,7 @@ int run_extract(ta_ctx* c) {
     // the sweep kernel alone (what the roofline is quoted on): the two events ride on the sweep's own launches
     // (begin / end timestamps of the dispatch, no event-record packets on the queue); the naive kernel gets plain records
     const bool own_dims = c->mdims[0] - c->first_owned > 0 && c->mdims[1] > 0 && c->mdims[2] > 0;
+    if (tune >= 0) TA_HIP(hipEventRecord(c->tune_ev[2 * tune], c->stream));
     if (c->impl == 1 || !own_dims) {
         if (ev_a) TA_HIP(hipEventRecord(ev_a, c->stream));
         if (c->impl == 1) ta::launch_naive(c->stream, a, c->itemsize, c->feature_mask);
@@ -256,6 +302,7 @@ int run_extract(ta_ctx* c) {
     } else {
         ta::launch_scan(c->stream, a, c->itemsize, c->feature_mask, ev_a, ev_b);
     }
+    if (tune >= 0) TA_HIP(hipEventRecord(c->tune_ev[2 * tune + 1], c->stream));
     // Without adjacency the LAST kernel of the step (the hot-row fold) mirrors the flag words into host-mapped memory
     // itself: no device-to-host copy (a blit kernel and a queue barrier) at the end of the step.  With adjacency the pair
     // count is final only when the collect kernel has ended; letting its last block publish it was measured and costs
@@ -357,6 +404,7 @@ TA_API int ta_ctx_create(int device_id, ta_ctx** out) {
     for (auto& ev : c->ev) if (e == hipSuccess) e = hipEventCreate(&ev);
     try { c->ring.assign(2, nullptr); } catch (...) { rc = fail(TA_ENOMEM, "out of host memory"); }
     for (auto& ev : c->ring) if (e == hipSuccess && rc == TA_OK) e = hipEventCreate(&ev);
+    for (auto& ev : c->tune_ev) if (e == hipSuccess && rc == TA_OK) e = hipEventCreate(&ev);
     if (e == hipSuccess) rc = c->small.reserve(SMALL_WORDS * sizeof(uint32_t));
     if (e == hipSuccess && rc == TA_OK) e = hipHostMalloc((void**)&c->h_small, SMALL_WORDS * sizeof(uint32_t), hipHostMallocMapped);
     if (e == hipSuccess && rc == TA_OK) {
@@ -391,6 +439,7 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ring) if (e) (void)hipEventDestroy(e);
+    for (auto& e : c->tune_ev) if (e) (void)hipEventDestroy(e);
     if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return TA_OK;
@@ -428,6 +477,11 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
         case TA_OPT_PAIR_SLOTS:
             if (value != 0 && (value < 4 || value > 30)) return fail(TA_EINVAL, "TA_OPT_PAIR_SLOTS must be 0 or in [4,30]");
             c->opt_pair_log2 = (int)value; return TA_OK;
+        case TA_OPT_SWEEP_SHAPE:
+            if (value < -1 || value > 1) return fail(TA_EINVAL, "TA_OPT_SWEEP_SHAPE is -1 (measure), 0 or 1");
+            c->opt_shape = (int)value;
+            c->auto_tile_shift = 0;
+            return TA_OK;
         case TA_OPT_VOLUME_SLACK:
             if (value < 0) return fail(TA_EINVAL, "TA_OPT_VOLUME_SLACK must be >= 0");
             c->volume_slack = value; return TA_OK;
@@ -459,9 +513,11 @@ TA_API int ta_ctx_get_option(ta_ctx* c, int key, int64_t* value) {
     switch (key) {
         case TA_OPT_IMPL: *value = c->impl; return TA_OK;
         case TA_OPT_VOLUME_SLACK: *value = c->volume_slack; return TA_OK;
+        case TA_OPT_SWEEP_SHAPE: *value = c->opt_shape; return TA_OK;
+        case TA_OPT_SWEEP_SHAPE_USED: *value = c->last_shape; return TA_OK;
         case TA_OPT_TIMING: *value = c->timing; return TA_OK;
         case TA_OPT_TIMING_RING: *value = (int64_t)(c->ring.size() / 2); return TA_OK;
-        case TA_OPT_TILE_PLANES: *value = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY, c->itemsize); return TA_OK;
+        case TA_OPT_TILE_PLANES: *value = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY, c->itemsize, c->opt_shape >= 0 ? c->opt_shape : (c->shape_pick >= 0 ? c->shape_pick : 1)); return TA_OK;
         case TA_OPT_PAIR_SLOTS: *value = c->pkeys.p ? c->pair_log2 : c->opt_pair_log2; return TA_OK;
         default: return fail(TA_EINVAL, "unknown option key %d", key);
     }

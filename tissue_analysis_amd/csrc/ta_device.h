@@ -35,6 +35,7 @@ struct SweepArgs {
     int64_t a_origin;        // global axis-0 coordinate of buffer plane `first_owned`
     int32_t first_owned;     // 0, or 1 when plane 0 is the low halo of a slab
     int32_t tile_planes;     // owned planes walked by one workgroup
+    int32_t shape;           // uint32 volumes with adjacency: 0 = two rows of 256 columns a wave, 1 = two rows of 512 (kernels_scan.hip)
     int32_t vec_ok;          // 16-byte loads allowed: rows are 16-byte aligned, or the buffer is the library's own (gfx950 loads
                              // 16 bytes from any address; a strip that straddles the last row's end reads into the buffer's slack)
     uint32_t max_label;

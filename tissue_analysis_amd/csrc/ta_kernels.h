@@ -105,7 +105,7 @@ void launch_synth(hipStream_t s, void* out, int itemsize, const int64_t dims[3],
 void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask, hipEvent_t ev_start = nullptr,
                  hipEvent_t ev_stop = nullptr);
 uint64_t sweep_grid_size(const SweepArgs& a, int itemsize, bool adjacency);   // workgroups of the sweep kernels of that feature class
-int sweep_default_tile_planes(bool adjacency, int itemsize);
+int sweep_default_tile_planes(bool adjacency, int itemsize, int shape);
 int sweep_max_tile_planes();
 
 }  // namespace ta
