@@ -1453,7 +1453,7 @@ uint64_t sweep_grid_size(const SweepArgs& a, int itemsize, bool adjacency) {
 // they walk twice the planes for the same voxels per workgroup (40 and 48 measure the same, 24 is 3 % slower, 64 1 %).
 // (The wide uint32 tiles -- 8 rows x 512 columns -- hold twice the voxels a plane: 32 planes measure best on C4 and C5, and at
 //  48 the tissue-filled volume overflows the workgroup tables.)
-int sweep_default_tile_planes(bool adjacency, int itemsize, int shape) { return adjacency ? (itemsize == 4 ? (shape ? 32 : 48) : 24) : 16; }
+int sweep_default_tile_planes(bool adjacency, int itemsize, int shape) { return adjacency ? (itemsize == 4 ? (shape ? 32 : 48) : 32) : 16; }
 int sweep_max_tile_planes() { return MAX_TILE_PLANES; }
 
 void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask, hipEvent_t ev_start, hipEvent_t ev_stop) {
