@@ -1443,9 +1443,13 @@ constexpr int RB32_ADJ = 2, RB32_MOM = 4;
 #define TA_U16_VPL 8
 #endif
 constexpr int VPL16_ADJ = TA_U16_VPL;
+#ifndef TA_U16_MOM_RB
+#define TA_U16_MOM_RB 2      // rows a wave of the moments-only uint16 kernel (512 columns each)
+#endif
+constexpr int RB16_MOM = TA_U16_MOM_RB;
 
 uint64_t sweep_grid_size(const SweepArgs& a, int itemsize, bool adjacency) {
-    const ScanSplit sp = itemsize == 2 ? (adjacency ? scan_split<VPL16_ADJ, 2>(a, 2) : scan_split<8, 2>(a, 2)) : (adjacency ? (a.shape ? scan_split<8, RB32_ADJ>(a, 4) : scan_split<4, RB32_ADJ>(a, 4)) : scan_split<4, RB32_MOM>(a, 4));
+    const ScanSplit sp = itemsize == 2 ? (adjacency ? scan_split<VPL16_ADJ, 2>(a, 2) : scan_split<8, RB16_MOM>(a, 2)) : (adjacency ? (a.shape ? scan_split<8, RB32_ADJ>(a, 4) : scan_split<4, RB32_ADJ>(a, 4)) : scan_split<4, RB32_MOM>(a, 4));
     return (uint64_t)sp.tiles_c * sp.tiles_b * sp.nbands;
 }
 // measured on C4 / C5 (profiles/r03_ablations.txt, gpurun_out/r3_rb2_tp.txt): shorter tiles = more workgroups to balance over
@@ -1461,8 +1465,8 @@ void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t featu
     if (itemsize == 2) {
         if (adj && mom2)       launch_scan_tt<uint16_t, VPL16_ADJ, 2, true, true>(s, a, ev_start, ev_stop);
         else if (adj)          launch_scan_tt<uint16_t, VPL16_ADJ, 2, true, false>(s, a, ev_start, ev_stop);
-        else if (mom2)         launch_scan_tt<uint16_t, 8, 2, false, true>(s, a, ev_start, ev_stop);
-        else                   launch_scan_tt<uint16_t, 8, 2, false, false>(s, a, ev_start, ev_stop);
+        else if (mom2)         launch_scan_tt<uint16_t, 8, RB16_MOM, false, true>(s, a, ev_start, ev_stop);
+        else                   launch_scan_tt<uint16_t, 8, RB16_MOM, false, false>(s, a, ev_start, ev_stop);
     } else {
         if (adj && mom2)       { if (a.shape) launch_scan_tt<uint32_t, 8, RB32_ADJ, true, true>(s, a, ev_start, ev_stop); else launch_scan_tt<uint32_t, 4, RB32_ADJ, true, true>(s, a, ev_start, ev_stop); }
         else if (adj)          { if (a.shape) launch_scan_tt<uint32_t, 8, RB32_ADJ, true, false>(s, a, ev_start, ev_stop); else launch_scan_tt<uint32_t, 4, RB32_ADJ, true, false>(s, a, ev_start, ev_stop); }
