@@ -96,6 +96,8 @@ def _worker(rank, world, port, dims, n_cells, seed, dtype_name, q, capacity=None
     ((37, 40, 264), 20000, "uint32", None, 0, 1, 0x17, False),   # tiny cells (table spills) WITHOUT second moments: sum2 must read as zero
     ((37, 40, 264), 50, "uint32", None, 0, 1, 31, True),      # slabs cut by cost (ta_volume_plane_events), sums reduce-scattered
     ((21, 24, 520), 30, "uint16", None, 0, 2, 31, True),      # ... two steps in flight
+    ((23, 24, 1024), 60, "uint32", None, 0, 1, 31, False),    # rows of whole 512-column tiles: the slabs' sweeps take turns between the two tile shapes
+    ((23, 24, 1024), 60, "uint32", None, 0, 2, 31, True),     # ... cost-balanced, reduce-scattered, two steps in flight
 ])
 def test_two_ranks_on_one_gpu_match_unsharded(dims, n_cells, dtype_name, capacity, pair_slots, depth, features, balanced):
     world = 2
