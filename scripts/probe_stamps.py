@@ -15,6 +15,9 @@ ctx = dev.torch_context(0)
 vol, L = dev.synth_slab(ctx, dims, dtype, c["n_cells"], c["seed"], ellipsoid="--no-ellipsoid" not in sys.argv)
 torch.cuda.synchronize()
 ctx.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, keep=vol)
+for a in sys.argv:                                   # --shape=0|1: TA_OPT_SWEEP_SHAPE
+    if a.startswith("--shape="):
+        ctx.set_option(_capi.OPT_SWEEP_SHAPE, int(a.split("=")[1]))
 for feats in (0x1f,):
     for _ in range(3):
         ctx.extract(feats, L)

@@ -393,11 +393,12 @@ __device__ __forceinline__ uint32_t label_probe_issue(LDS& S, const bool pend, u
 #ifndef TA_ABL_HOT
 #define TA_ABL_HOT 0
 #endif
-// the first two groups (128 records) of a face buffer that holds at least that many
-template <typename LDS, typename WLDS>
+// the first NF groups of 64 records of a face buffer that holds at least that many and at most 64 more (NF = 2: 128 .. 192,
+// NF = 1: 64 .. 127 -- what is left moves to the front, one record per lane)
+template <int NF, typename LDS, typename WLDS>
 __device__ __forceinline__ void drain_face_groups(const SweepArgs* kp, LDS& S, WLDS& W, int lane, uint32_t& fcount) {
-    constexpr int NF = 2;
-    static_assert(FCAP >= 64 * NF && FCAP <= 64 * (NF + 1), "what is left after the groups moves to the front one record per lane");
+    static_assert(NF == 1 || NF == 2, "one or two lookups per lane in lockstep");
+    static_assert(FCAP >= 64 * NF && FCAP <= 64 * 3, "what is left after the groups moves to the front one record per lane");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (TA_ABLATE >= 1) { fcount = 0u; return; }
 #ifdef TA_ABL_NOHOT
@@ -444,14 +445,17 @@ __device__ __forceinline__ void drain_face_groups(const SweepArgs* kp, LDS& S, W
     bool spill = false;
 #if !defined(TA_ABL_NOLOOP) && TA_ABL_HOT < 2
 #pragma nounroll
-    for (uint32_t round = 1u; __builtin_amdgcn_ballot_w64(pend[0] | pend[1]); ++round) {
-        static_assert(NF == 2, "two lookups per lane in lockstep");
+    for (uint32_t round = 1u; __builtin_amdgcn_ballot_w64(pend[0] | pend[NF - 1]); ++round) {
         if (round >= (uint32_t)PPROBE) { spill = true; break; }
         const uint64_t r0 = pair_probe_issue(S, pend[0], slot[0], k[0], key[0]);
-        const uint64_t r1 = pair_probe_issue(S, pend[1], slot[1], k[1], key[1]);
         // (a compare-and-swap that gave EMPTY back has put the key there; a plain read that gives EMPTY has found a free slot)
-        k[0] = (!TA_PROBE_NORTN && r0 == EMPTY_KEY) ? key[0] : r0; k[1] = (!TA_PROBE_NORTN && r1 == EMPTY_KEY) ? key[1] : r1;
-        pend[0] = pend[0] && k[0] != key[0]; pend[1] = pend[1] && k[1] != key[1];
+        if constexpr (NF == 2) {
+            const uint64_t r1 = pair_probe_issue(S, pend[1], slot[1], k[1], key[1]);
+            k[1] = (!TA_PROBE_NORTN && r1 == EMPTY_KEY) ? key[1] : r1;
+            pend[1] = pend[1] && k[1] != key[1];
+        }
+        k[0] = (!TA_PROBE_NORTN && r0 == EMPTY_KEY) ? key[0] : r0;
+        pend[0] = pend[0] && k[0] != key[0];
     }
 #endif
 #pragma unroll
@@ -688,6 +692,14 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #endif
 #ifndef TA_DRAIN_ALL_U16
 #define TA_DRAIN_ALL_U16 1    // the full tiles of uint16 volumes too (their kernel sits at 125 VGPRs: see the build's register check)
+#endif
+// TA_FDRAIN1: tiles of eight voxels a lane put twice the records of a plane step into the same buffers; with 64 .. 127 faces
+// left after a step, the next one's often do not fit and the whole buffer goes through the in-plane drain (29 % of C4's face
+// records, 43 % of the tissue-filled volume's, against 13 / 14 % with four voxels a lane).  With one group of 64 leaving at
+// the top of the plane those shares fall to 7 / 16 % -- and the sweep takes the same time (C4 1.01 / 1.02 vs 1.01 / 1.02 ms,
+// filled 1.38 - 1.44 vs 1.39 - 1.46, C5 6.79 / 6.83 vs 6.78 / 6.86): where a record is drained does not matter.  Off.
+#ifndef TA_FDRAIN1
+#define TA_FDRAIN1 0
 #endif
 #ifndef TA_FDRAIN
 #define TA_FDRAIN 128         // face records in the buffer from which the top-of-plane drain takes the full groups
@@ -1112,7 +1124,8 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     //      that kernel is bound by its instructions per voxel, not by the bytes it has in flight.)
     auto top_drains = [&]() {
         if constexpr (DRAIN_ALL) {
-            if (fcount >= (uint32_t)TA_FDRAIN) drain_face_groups<LDS>(kp, S, W, lane, fcount);
+            if (fcount >= (uint32_t)TA_FDRAIN) drain_face_groups<2, LDS>(kp, S, W, lane, fcount);
+            else if (TA_FDRAIN1 && VPL == 8 && fcount >= 64u) drain_face_groups<1, LDS>(kp, S, W, lane, fcount);   // (the wide tiles: see TA_FDRAIN1)
             if (rcount > 64u) drain_run_group<MOM2, LDS>(kp, S, W, EDGE, lane, rcount, first_label);
         }
     };
@@ -1142,9 +1155,11 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                 // the hot drains: between two planes a wave holds nothing but the plane before (and the next one is in flight)
 #ifdef TA_RECCOUNT
                 if (lane == 0 && fcount >= (uint32_t)TA_FDRAIN) atomicAdd(&cold_args(kp)->flags[11], 128u);
+                else if (lane == 0 && TA_FDRAIN1 && VPL == 8 && fcount >= 64u) atomicAdd(&cold_args(kp)->flags[11], 64u);
                 if (lane == 0 && rcount > 64u) atomicAdd(&cold_args(kp)->flags[12], 64u);
 #endif
-                if (fcount >= (uint32_t)TA_FDRAIN) drain_face_groups<LDS>(kp, S, W, lane, fcount);
+                if (fcount >= (uint32_t)TA_FDRAIN) drain_face_groups<2, LDS>(kp, S, W, lane, fcount);
+                else if (TA_FDRAIN1 && VPL == 8 && fcount >= 64u) drain_face_groups<1, LDS>(kp, S, W, lane, fcount);
                 if (rcount > 64u) drain_run_group<MOM2, LDS>(kp, S, W, EDGE, lane, rcount, first_label);
             }
             if constexpr (PINB != 0) {
