@@ -113,6 +113,34 @@ def cpu_best_effort(vol_tensor, dims, dtype, max_label, planes=256, workers=16):
                                                                                       len(jobs), dt))
 
 
+def _launch_ranks(n):
+    """`python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same arguments>` as a child process."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for out in proc.stdout:                       # (rank 0 prints ONE JSON line; anything else on stdout goes to stderr)
+        text = out.strip()
+        if text.startswith("{") and '"metric"' in text:
+            line = text
+        elif text:
+            sys.stderr.write(out)
+    rc = proc.wait()
+    if line is not None:
+        print(line, flush=True)
+    elif rc == 0:
+        sys.stderr.write("bench.py: the ranks exited without a result line\n")
+        rc = 1
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +156,11 @@ def main():
     ap.add_argument("--tile-planes", type=int, default=0)
     ap.add_argument("--dims", type=int, nargs=3, default=None, help="rehearsal: override the volume shape")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # A plain `python bench.py --gpus N`: start the N ranks ourselves, as a CHILD process (nothing here has touched the
+        # GPU yet, and a child is safe either way), relay rank 0's JSON line and the launcher's return code.
+        sys.exit(_launch_ranks(args.gpus))
 
     import torch
     import torch.distributed as dist

@@ -18,7 +18,7 @@ for v in "$@"; do
     D=$R/gpurun_out/pmcsets_${TAG}_${v}_$i
     rocprofv3 --pmc $set --output-format csv -d $D -- python3 $R/scripts/probe_impls.py C4 --impl 0 --feat 0x1f --iters 4 --no-check $PMC_PROBE_ARGS > $D.log 2>&1 || echo "$v pass $i failed" >> $OUT
     echo "## $v" >> $OUT
-    python3 $R/scripts/pmc_summary.py --kernel "scan_two_rows_kernel|scan_kernel" $D | grep -v "^==" >> $OUT 2>&1
+    python3 $R/scripts/pmc_summary.py --kernel "scan_two_rows_kernel|scan_kernel|scan_wide_kernel" $D | grep -v "^==" >> $OUT 2>&1
     rm -rf $D
   done
 done

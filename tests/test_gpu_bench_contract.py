@@ -51,3 +51,18 @@ def test_bench_two_ranks_rehearsal_runs_the_multi_gpu_path():
     cuts = d["config"]["slab_cuts"]
     assert cuts[0] == 0 and cuts[-1] == 96 and len(cuts) == 3 and 0 < cuts[1] < 96
     assert d["config"]["steps_in_flight"] == 2 and d["roofline"]["frac"] > 0 and "global_adjacency_gather_ms" in d["secondary"]
+
+
+def test_bench_gpus_2_as_a_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher around it (how the driver starts the N = 1 bench): bench.py starts
+    `torch.distributed.run` itself as a child process, relays rank 0's one JSON line and the return code."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(TA_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dims", "96", "64", "512",
+                        "--steps", "3", "--warmup", "1", "--settle-ms", "5"], cwd=ROOT, env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode == 0, p.stderr.decode(errors="replace")[-2000:]
+    lines = [l for l in p.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{")
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["steps_in_flight"] == 2 and d["roofline"]["frac"] > 0

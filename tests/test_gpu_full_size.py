@@ -238,16 +238,34 @@ def test_c5_on_one_gpu_identities_windows_and_virtual_slabs():
         assert np.array_equal(merged[k], whole[k]), "8 slabs vs unsharded: " + k
     del merged, parts
 
-    # -- the WHOLE 2048^3 volume against the C oracle: 34 GB to the host, 16 forked workers over Z-slabs
-    #    (~0.5 Gvoxel/s) + merge; every integer array bit-exact.  Needs the volume in host memory next to the workers' results.
+
+def test_c5_whole_volume_against_the_c_oracle(capsys):
+    """The WHOLE 2048^3 volume against the C oracle: 34 GB to the host, 16 forked workers over Z-slabs (~0.5 Gvoxel/s) +
+    merge; every integer array bit-exact.  Needs the volume in host memory next to the workers' results: SKIPPED (visibly,
+    with the reason) on a host without ~46 GB available.  Its one-line result is printed past pytest's capture so that the
+    tail of the driver's GPU-test record shows whether it ran."""
     import os
     import time
     import psutil
-    need = vol.numel() * vol.element_size() + (12 << 30)
-    if psutil.virtual_memory().available < need:
-        print("C5 in full against the oracle: SKIPPED, %.0f GB of host memory available, %.0f needed"
-              % (psutil.virtual_memory().available / 2 ** 30, need / 2 ** 30))
-        return
+    import torch
+    c = synth.CONFIGS["C5"]
+    dims, dtype = c["dims"], np.dtype(c["dtype"])
+    need = int(np.prod(dims)) * dtype.itemsize + (12 << 30)
+    avail = psutil.virtual_memory().available
+    if avail < need:
+        msg = "C5 in full against the oracle: SKIPPED, %.0f GB of host memory available, %.0f needed" % (avail / 2 ** 30, need / 2 ** 30)
+        with capsys.disabled():
+            print("\n[" + msg + "]")
+        pytest.skip(msg)
+    ctx = dev.torch_context(0)
+    vol, L = dev.synth_slab(ctx, dims, dtype, c["n_cells"], c["seed"])
+    torch.cuda.synchronize()
+    ctx.set_volume_device(vol.data_ptr(), dtype.itemsize, vol.shape, keep=vol)
+    ctx.extract(_capi.F_ALL, L)
+    whole = fetch(ctx, L)
+    dbg = ctx.debug_counters()
+    assert dbg["range_flag"] == 0 and dbg["pair_overflow"] == 0
+    ctx.close()
     t0 = time.perf_counter()
     host = vol.cpu().numpy().view(dtype)
     del vol
@@ -255,9 +273,10 @@ def test_c5_on_one_gpu_identities_windows_and_virtual_slabs():
     t1 = time.perf_counter()
     want = onepass_c_parallel(host, L, workers=min(16, os.cpu_count() or 1))
     t2 = time.perf_counter()
-    print("C5 in full against the oracle: %.1f s to the host, %.1f s oracle (%d labels, %d pairs)"
-          % (t1 - t0, t2 - t1, int((want["count"] > 0).sum()), want["pair_lo"].size))
     assert_same_accumulators(whole, want, "C5 2048^3 full feature set, whole volume")
+    with capsys.disabled():
+        print("\n[C5 in full against the oracle: %d labels, %d pairs equal (every integer array); %.1f s to the host, %.1f s oracle]"
+              % (int((want["count"] > 0).sum()), want["pair_lo"].size, t1 - t0, t2 - t1))
 
 
 def test_c5_exchange_budget_eight_contexts_on_one_gpu(capsys):

@@ -101,6 +101,66 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
     return x;
 }
 
+// ---- record stores by the exec mask itself ----------------------------------------------------------
+// A compare position of the emit pass used to cost five vector instructions whether or not it fired: compare, select the
+// address (own offset or trash slot), select the step (8 or 0), store, add the step -- plus the wait states between a
+// VCC write and its readers.  The sweep is bound by its vector instructions wherever there is tissue (profiles/NOTES.md,
+// round 5), so the stores are predicated the cheap way instead: v_cmpx writes the compare straight into EXEC, the store and
+// the step of the offset run in the lanes that fired, one scalar move puts EXEC back: two vector instructions a position.
+// (Inline asm: the compiler never sees EXEC change.  No manual wait states are needed between a VALU write of EXEC and
+// LDS / VALU instructions that run under it; DPP instructions are the exception -- emit_done() pads for them.)
+#ifndef TA_MASKED_STORES
+#define TA_MASKED_STORES 7      // bits: 1 = the plane's axis-0 faces, 2 = a row's axis-1 faces, 4 = its runs
+#endif
+// FULL: every lane of the wave is live at the call (EXEC is put back to all ones), else `live` is the mask to put back
+#ifndef TA_CMPX_STYLE
+#define TA_CMPX_STYLE 0
+#endif
+#if TA_CMPX_STYLE == 0
+#define TA_CMPX(a, b) "v_cmpx_ne_u32_e32 vcc, " a ", " b "\n\t"
+#define TA_CMPX_PART(a, b) TA_CMPX(a, b)
+#elif TA_CMPX_STYLE == 1
+#define TA_CMPX(a, b) "v_cmpx_ne_u32_e32 vcc, " a ", " b "\n\ts_nop 4\n\t"
+#define TA_CMPX_PART(a, b) TA_CMPX(a, b)
+#else
+#define TA_CMPX(a, b) "v_cmp_ne_u32_e32 vcc, " a ", " b "\n\ts_mov_b64 exec, vcc\n\t"
+#define TA_CMPX_PART(a, b) "v_cmp_ne_u32_e32 vcc, " a ", " b "\n\ts_and_b64 exec, exec, vcc\n\t"
+#endif
+template <bool FULL>
+__device__ __forceinline__ void store_face_if_ne(uint32_t& off, const uint32_t v, const uint32_t pv, const uint64_t live) {
+    if constexpr (FULL)
+        asm volatile(TA_CMPX("%1", "%2") "ds_write2_b32 %0, %1, %2 offset1:1\n\tv_add_u32_e32 %0, 8, %0\n\ts_mov_b64 exec, -1"
+                     : "+v"(off) : "v"(v), "v"(pv) : "vcc", "memory");
+    else
+        asm volatile(TA_CMPX_PART("%1", "%2") "ds_write2_b32 %0, %1, %2 offset1:1\n\tv_add_u32_e32 %0, 8, %0\n\ts_mov_b64 exec, %3"
+                     : "+v"(off) : "v"(v), "v"(pv), "s"(live) : "vcc", "memory");
+}
+// ... the neighbour word tagged with the axis (`tag`: wave-uniform)
+template <bool FULL>
+__device__ __forceinline__ void store_face_tagged_if_ne(uint32_t& off, const uint32_t v, const uint32_t pv, const uint32_t tag, const uint64_t live) {
+    uint32_t t;
+    if constexpr (FULL)
+        asm volatile(TA_CMPX("%2", "%3") "v_or_b32_e32 %1, %4, %3\n\tds_write2_b32 %0, %2, %1 offset1:1\n\tv_add_u32_e32 %0, 8, %0\n\ts_mov_b64 exec, -1"
+                     : "+v"(off), "=&v"(t) : "v"(v), "v"(pv), "s"(tag) : "vcc", "memory");
+    else
+        asm volatile(TA_CMPX_PART("%2", "%3") "v_or_b32_e32 %1, %4, %3\n\tds_write2_b32 %0, %2, %1 offset1:1\n\tv_add_u32_e32 %0, 8, %0\n\ts_mov_b64 exec, %5"
+                     : "+v"(off), "=&v"(t) : "v"(v), "v"(pv), "s"(tag), "s"(live) : "vcc", "memory");
+}
+// a run record {closing label, code0 | J} where v != pcv; the two run arrays lie STRIDE dwords apart
+template <bool FULL, int J, int STRIDE>
+__device__ __forceinline__ void store_run_if_ne(uint32_t& off, const uint32_t v, const uint32_t pcv, const uint32_t code0, const uint64_t live) {
+    static_assert(STRIDE < 256, "ds_write2_b32 offsets are 8 bits of dwords");
+    uint32_t t;
+    if constexpr (FULL)
+        asm volatile(TA_CMPX("%2", "%3") "v_or_b32_e32 %1, %5, %4\n\tds_write2_b32 %0, %3, %1 offset1:%6\n\tv_add_u32_e32 %0, 4, %0\n\ts_mov_b64 exec, -1"
+                     : "+v"(off), "=&v"(t) : "v"(v), "v"(pcv), "v"(code0), "n"(J), "n"(STRIDE) : "vcc", "memory");
+    else
+        asm volatile(TA_CMPX_PART("%2", "%3") "v_or_b32_e32 %1, %5, %4\n\tds_write2_b32 %0, %3, %1 offset1:%6\n\tv_add_u32_e32 %0, 4, %0\n\ts_mov_b64 exec, %7"
+                     : "+v"(off), "=&v"(t) : "v"(v), "v"(pcv), "v"(code0), "n"(J), "n"(STRIDE), "s"(live) : "vcc", "memory");
+}
+// behind the last predicated store of a row: a DPP instruction needs five wait states after a VALU write of EXEC
+__device__ __forceinline__ void emit_done() { asm volatile("s_nop 4" ::: "memory"); }
+
 // ---- workgroup tables, with the kernel arguments kept OUT of the hot loop -----------------------
 // The sweep kernels are short of SGPRs: the twenty-odd kernel arguments that only the cold paths need
 // (global rows, pair table, flags) are re-read from the kernarg segment where they are used.  The
@@ -460,7 +520,11 @@ __device__ __forceinline__ void drain_face_groups(const SweepArgs* kp, LDS& S, W
 #endif
 #pragma unroll
     for (int g = 0; g < NF; ++g) {
+#ifdef TA_ABL_SHARE1
+        if (TA_ABL_HOT < 1) { if (live[g] && !pend[g]) pcnt_add(S, (slot[g] + (uint32_t)lane * 7u) & (PSLOTS - 1), rec[g].y >> 30); }
+#else
         if (TA_ABL_HOT < 1) { if (live[g] && !pend[g]) pcnt_add(S, slot[g], rec[g].y >> 30); }
+#endif
         else asm volatile("" :: "v"(slot[g]), "s"(__builtin_amdgcn_ballot_w64(live[g] && !pend[g])));
         if (spill) {          // (wave-uniform: the probe limit was reached with lookups still open)
             if (pend[g]) { const SweepArgs* A = cold_args(kp); pair_spill_global(A->pairs, A->flags, lo[g], hi[g], rec[g].y >> 30, 1u); }
@@ -539,15 +603,21 @@ __device__ __forceinline__ void drain_run_group(const SweepArgs* kp, LDS& S, WLD
     uint4 cur = {0u, 0u, 0u, 0xffffu};
     uint2 cur2 = {0xffffu, 0xffffu};
     if (TA_ABL_HOT < 1) {
+#ifndef TA_ABL_NOBOXHOT
         cur = *reinterpret_cast<const uint4*>(boxr);              // min a,b,c | max a
         cur2 = *reinterpret_cast<const uint2*>(boxr + 4);         // max b,c
+#endif
         if (plive && !ppend) pcnt_add(S, pslot, 2u);
     } else asm volatile("" :: "v"(pslot), "s"(__builtin_amdgcn_ballot_w64(plive && !ppend)));
     const uint32_t bl = (code >> 10) & 15u, al = (code >> 14) & 63u;
     const RunSums L = run_sums<MOM2>(c0, kk - c0, al, bl);
     if (TA_ABL_HOT >= 1) asm volatile("" :: "v"(L.n), "v"(L.sa), "v"(L.sb), "v"(L.sc), "v"(L.saa), "v"(L.sab), "v"(L.sac), "v"(L.sbb), "v"(L.sbc), "v"(L.scc), "v"(lslot), "s"(__builtin_amdgcn_ballot_w64(llive && !lpend)));
     if (TA_ABL_HOT < 1 && llive && !lpend) {
+#ifdef TA_ABL_SHARE1       // (ablation: every lane its own row -- no two lanes of an atomic share an address)
+        unsigned long long* row = (unsigned long long*)&S.lsum[((lslot + (uint32_t)lane) & (LSLOTS - 1)) * NW];
+#else
         unsigned long long* row = (unsigned long long*)&S.lsum[lslot * NW];
+#endif
         atomicAdd(row + 0, (unsigned long long)((uint64_t)L.n | ((uint64_t)L.sb << 32)));
         atomicAdd(row + 1, (unsigned long long)((uint64_t)L.sa | ((uint64_t)L.sc << 32)));
         if (MOM2) {
@@ -557,7 +627,11 @@ __device__ __forceinline__ void drain_run_group(const SweepArgs* kp, LDS& S, WLD
             atomicAdd(row + (MOM2 ? 5 : 0), (unsigned long long)L.scc);
         }
         // bounding box: touched only when this run extends it (almost every run lies inside the box its label already has)
+#ifdef TA_ABL_NOBOXHOT
+        const bool grows = false;
+#else
         const bool grows = (al < cur.x) | (bl < cur.y) | (c0 < cur.z) | (al > cur.w) | (bl > cur2.x) | (kk - 1u > cur2.y);
+#endif
         if (grows) {
             uint32_t* box = &S.lbox[lslot * 8];
             atomicMin(box + 0, al); atomicMin(box + 1, bl); atomicMin(box + 2, c0);
@@ -841,8 +915,8 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     const uint32_t fbase = (uint32_t)(uintptr_t)&W.frec[0];
     const uint32_t rbase = (uint32_t)(uintptr_t)&W.cql[1];
     constexpr uint32_t RSTRIDE = (RCAP + 2) * 4u;         // bytes between the two run arrays
-    const uint32_t ftrash = (uint32_t)(uintptr_t)&W.frec[FTRASH];   // where the stores of compares that did not fire go
-    const uint32_t rtrash = (uint32_t)(uintptr_t)&W.cql[RTRASH];
+    [[maybe_unused]] const uint32_t ftrash = (uint32_t)(uintptr_t)&W.frec[FTRASH];   // where the stores of compares that did not fire go (TA_MASKED_STORES: nowhere)
+    [[maybe_unused]] const uint32_t rtrash = (uint32_t)(uintptr_t)&W.cql[RTRASH];
 
     // Leading rows of the tile that are one label (the label of its first voxel) from end to end are not records:
     // they are counted and added in closed form at the end -- that is the whole cost of background.
@@ -879,7 +953,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                 continue;
             }
             const uint32_t excl = incl - mine;
-            if (insel) emit(fbase + ((fcount + (excl & 0xffffu)) << 3), rbase + ((rcount + (excl >> 16)) << 2));
+            if (insel) emit(fbase + ((fcount + (excl & 0xffffu)) << 3), rbase + ((rcount + (excl >> 16)) << 2), std::false_type{});
             fcount += rowf; rcount += rowr;
             if (hi >= 64u) break;
             lo = hi; hi = 64u;
@@ -905,7 +979,7 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         const uint32_t offf = fbase + ((fcount + (excl & 0xffffu)) << 3);     // LDS address of the lane's next face record
         const uint32_t offr = rbase + ((rcount + (excl >> 16)) << 2);         // ... and of its next run record (first array)
         fcount += rowf; rcount += rowr;
-        if (TA_ABLATE < 2) emit(offf, offr);
+        if (TA_ABLATE < 2) emit(offf, offr, std::true_type{});      // (straight-line code: every lane is live)
     };
     // A new plane has landed: its faces with the plane before it (axis 0) are counted and stored TOGETHER with the events of
     // its first row -- one scan of the lanes' counts instead of two (`old` = the plane before, kept until that row is done).
@@ -920,12 +994,16 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #endif
         return cf;
     };
-    auto emit_plane_faces = [&](uint32_t& offf) {
+    auto emit_plane_faces = [&](uint32_t& offf, const uint64_t live, auto full) {
 #ifndef TA_ABL_NOFACE0
 #pragma unroll
         for (int r = 0; r < RB; ++r)
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
+#if TA_MASKED_STORES & 1
+                store_face_if_ne<decltype(full)::value>(offf, cur[r][j], old[r][j], live);
+                continue;
+#endif
                 uint32_t v = cur[r][j];
                 asm volatile("" : "+v"(v));               // (compare again: see the row emission)
                 const bool f = v != old[r][j];
@@ -1075,19 +1153,34 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
             if (__builtin_amdgcn_ballot_w64(cnt != 0u) == 0ull) continue;       // the common case: one branch per row
 #endif
             // ---- 2. + 3. offsets, then a firing lane stores at its own offset and steps it
-            place_records(cnt, [&](uint32_t offf, uint32_t offr) {
+            place_records(cnt, [&](uint32_t offf, uint32_t offr, auto full) {
                 // (laundered: keeps the tagged / coded copies of the row's registers out of long-lived registers)
                 uint32_t tag1 = 1u << 30;
                 uint32_t rowcode = (uint32_t)__builtin_amdgcn_readfirstlane((int)((bloc << 10) | (ploc << 14)));
                 if (ADJ) asm volatile("" : "+s"(tag1));
                 asm volatile("" : "+s"(rowcode));
-                if (ADJ && r == 0) { if (with_plane_faces) emit_plane_faces(offf); }
+                constexpr bool FULL = decltype(full)::value;
+                // (the lanes that are live here -- all of them on the straight-line path, a lane range in place_in_pieces.  Laundered: the
+                //  predicated stores put EXEC back from this COPY; handed the ballot itself, the compiler passes `exec` as the operand
+                //  and the restore becomes `s_mov_b64 exec, exec`)
+                uint64_t live = FULL ? ~0ull : __builtin_amdgcn_ballot_w64(true);
+                if (!FULL) asm volatile("" : "+s"(live));
+#ifdef TA_DBG_EMIT
+                const uint32_t dbg_off0 = offf;
+#endif
+                if (ADJ && r == 0) { if (with_plane_faces) emit_plane_faces(offf, live, full); }
+#ifdef TA_DBG_EMIT
+                if (ADJ && r == 0 && with_plane_faces) {
+                    const uint32_t wrote = (offf - dbg_off0) >> 3, want = count_plane_faces();
+                    if (wrote != want || (wrote != 0u && (offf > fbase + 8u * (uint32_t)FCAP || dbg_off0 < fbase))) {
+                        uint32_t* fl = cold_args(kp)->flags;
+                        if (atomicAdd(&fl[15], 1u) == 0u) { fl[8] = wrote; fl[9] = want; fl[10] = (uint32_t)lane; fl[11] = (dbg_off0 - fbase) >> 3; fl[12] = fcount; fl[13] = FULL ? 1u : 0u; fl[14] = (uint32_t)__builtin_amdgcn_ballot_w64(true); }
+                    }
+                }
+#endif
+                const uint32_t code0 = lane_c | rowcode;
 #pragma unroll
                 for (int j = 0; j < VPL; ++j) {
-                    // (an opaque copy: the compares are done again here instead of keeping a dozen 64-bit lane masks
-                    //  alive from the counting pass across the scan -- and across a drain -- in scarce SGPRs)
-                    uint32_t v = cur[r][j];
-                    asm volatile("" : "+v"(v));
 #ifndef TA_ABL_NOFACE1
                     if (ADJ && (r > 0 || !EDGE || has_up))
 #else
@@ -1095,19 +1188,44 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #endif
                     {
                         const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];
+#if TA_MASKED_STORES & 2
+                        store_face_tagged_if_ne<FULL>(offf, cur[r][j], pv, tag1, live);
+#else
+                        // (every lane stores at every compare without touching the exec mask: at its own offset when the compare
+                        //  fired, into a trash slot when it did not -- the pre-round-5 stores, kept for comparison)
+                        uint32_t v = cur[r][j];
+                        asm volatile("" : "+v"(v));
                         const bool f = v != pv;
                         const uint32_t at = f ? offf : ftrash;
                         *(lds_u32)(uintptr_t)at = v; *(lds_u32)(uintptr_t)(at + 4u) = pv | tag1;
                         offf += f ? 8u : 0u;
-                    }
-                    {
-                        const bool g = v != pcv[j];
-                        const uint32_t at = g ? offr : rtrash;
-                        *(lds_u32)(uintptr_t)at = pcv[j];
-                        *(lds_u32)(uintptr_t)(at + RSTRIDE) = (lane_c + (uint32_t)j) | rowcode;
-                        offr += g ? 4u : 0u;
+#endif
                     }
                 }
+                // (the runs behind the faces; records of a row in column order)
+#if TA_MASKED_STORES & 4
+                store_run_if_ne<FULL, 0, (int)(RSTRIDE / 4u)>(offr, cur[r][0], pcv[0], code0, live);
+                if constexpr (VPL > 1) store_run_if_ne<FULL, 1 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][1 % VPL], pcv[1 % VPL], code0, live);
+                if constexpr (VPL > 2) store_run_if_ne<FULL, 2 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][2 % VPL], pcv[2 % VPL], code0, live);
+                if constexpr (VPL > 3) store_run_if_ne<FULL, 3 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][3 % VPL], pcv[3 % VPL], code0, live);
+                if constexpr (VPL > 4) store_run_if_ne<FULL, 4 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][4 % VPL], pcv[4 % VPL], code0, live);
+                if constexpr (VPL > 5) store_run_if_ne<FULL, 5 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][5 % VPL], pcv[5 % VPL], code0, live);
+                if constexpr (VPL > 6) store_run_if_ne<FULL, 6 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][6 % VPL], pcv[6 % VPL], code0, live);
+                if constexpr (VPL > 7) store_run_if_ne<FULL, 7 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][7 % VPL], pcv[7 % VPL], code0, live);
+                static_assert(VPL <= 8, "the run stores are written out for eight voxels a lane");
+#else
+#pragma unroll
+                for (int j = 0; j < VPL; ++j) {
+                    uint32_t v = cur[r][j];
+                    asm volatile("" : "+v"(v));
+                    const bool g = v != pcv[j];
+                    const uint32_t at = g ? offr : rtrash;
+                    *(lds_u32)(uintptr_t)at = pcv[j];
+                    *(lds_u32)(uintptr_t)(at + RSTRIDE) = code0 | (uint32_t)j;
+                    offr += g ? 4u : 0u;
+                }
+#endif
+                if (TA_MASKED_STORES) emit_done();
                 if (need_end && lane == 63) {
                     *(lds_u32)(uintptr_t)offr = cur[r][VPL - 1];
                     *(lds_u32)(uintptr_t)(offr + RSTRIDE) = (uint32_t)TC | rowcode | ROW_END;

@@ -168,7 +168,11 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
 
     // -- the pairs, from the last thread down: the home slot of the pair in the device-global table is READ first and looked
     //    at afterwards (the first global round trip of the probe is in flight while the rest is prepared)
+#ifdef TA_ABL_NOFLUSH_PAIRS
+    if (false) {
+#else
     if (ADJ) {
+#endif
         for (int j = NT - 1 - tid; j < np; j += NT) {
             const int i = plist[j];
             const uint64_t key = S.pkeys[i];
@@ -189,7 +193,11 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
     }
     // -- the labels, from the first thread up
     uint64_t* const hot_rows = HOT ? hot_rows_of(A) : nullptr;
+#ifdef TA_ABL_NOFLUSH_LABELS
+    for (int j = tid; j < 0; j += NT) {
+#else
     for (int j = tid; j < nl; j += NT) {
+#endif
         const int i = llist[j];
         const uint32_t label = S.lkeys[i];
         const uint64_t w0 = S.lsum[i * NW + 0], w1 = S.lsum[i * NW + 1];

@@ -435,6 +435,7 @@ class SlabJob(object):
         torch = self._torch
         self.ctx.extract(self.features, self.max_label)
         if self.group is None:
+            self._unverified = True          # (finish() reads the range / overflow flags of the last extraction)
             return
         adj = self._adjacency_wanted()
         first = adj and (self._cap is None or self._send is None)
@@ -466,6 +467,12 @@ class SlabJob(object):
 
     def _finish(self):
         if not self._unverified:
+            return
+        if self.group is None:
+            # one rank: drain the stream and validate the flags of the last extraction (a label above max_label raises, a
+            # pair table that overflowed is grown and the extraction repeated inside the library)
+            self._unverified = False
+            self.ctx.adjacency_size()
             return
         import torch.distributed as dist
         from . import _capi
