@@ -58,6 +58,69 @@ def real_indices(slices, resolutions):
     return [(s.start * r, s.stop * r) for s, r in zip(slices, resolutions)]
 
 
+def wall(mask_img, label_id, device=0):
+    """Labels of the voxels of `mask_img` in the 6-connected one-voxel shell around cell `label_id`, in C index order -- what
+    `mask_img[binary_dilation(mask_img == label_id) - (mask_img == label_id)]` gives in the reference (SIA:45-52; nothing
+    outside the array counts, scipy's border value 0).  ONE 6-stencil pass of the HIP first-layer kernel over the array (the
+    labels are shifted by one on the way in so that a shell voxel labelled 0 stays distinguishable from "not in the shell")."""
+    a = np.asarray(mask_img)
+    if a.ndim not in (2, 3) or a.dtype.kind not in "ui":
+        raise ValueError("wall() takes a 2D / 3D integer label image")
+    if a.size == 0:
+        return a.ravel()
+    top = int(a.max())
+    if int(a.min()) < 0 or top > 0xFFFFFFFD or not 0 <= int(label_id) <= 0xFFFFFFFD:
+        raise ValueError("labels must lie in [0, 2^32 - 3]")
+    vol = np.ascontiguousarray(a if a.ndim == 3 else a[:, :, None]).astype(np.uint16 if top < 0xFFFF else np.uint32) + 1
+    with _capi.Context(device) as ctx:
+        ctx.set_volume(vol)
+        shell = ctx.first_layer(int(label_id) + 1, False, vol)         # the shifted labels of the shell, 0 elsewhere
+    return (shell[shell != 0] - 1).astype(a.dtype)
+
+
+def contact_surface(mask_img, label_id, device=0):
+    """The set of labels in contact with cell `label_id` in `mask_img` (SIA:55-60)."""
+    return set(np.unique(wall(mask_img, label_id, device)).tolist())
+
+
+def coordinates_centering3D(coordinates, mean=[]):
+    """Coordinates (3 x N, or N x 3) centred on their mean -- or on `mean` -- as a 3 x N array (SIA:123-135)."""
+    try:
+        x, y, z = coordinates
+    except (ValueError, TypeError):
+        x, y, z = np.asarray(coordinates).T
+    if len(mean) == 0:
+        mean = np.mean(np.array([x, y, z]), 1)
+    return np.array([x - mean[0], y - mean[1], z - mean[2]])
+
+
+def compute_covariance_matrix(coordinates):
+    """(1 / max(shape)) * P . P^T of a point set given as 3 x N (or N x 3 with N > 3) (SIA:137-150)."""
+    coordinates = np.asarray(coordinates)
+    if coordinates.shape[0] > 3:
+        coordinates = coordinates.T
+    return 1. / max(coordinates.shape) * np.dot(coordinates, coordinates.T)
+
+
+def eigen_values_vectors(cov_matrix):
+    """Eigenvalues in decreasing order and the eigenvectors BY ROWS of a covariance matrix of size <= 3 (SIA:152-167)."""
+    cov_matrix = np.asarray(cov_matrix)
+    assert max(cov_matrix.shape) <= 3
+    eig_val, eig_vec = np.linalg.eig(cov_matrix)
+    order = eig_val.argsort()[::-1]
+    return eig_val[order], np.array(eig_vec[:, order]).T
+
+
+def distance(ptsA, ptsB):
+    """Euclidean distance between two 2D or 3D points; None (with a warning) when their dimensions differ (SIA:169-188)."""
+    if len(ptsA) != len(ptsB):
+        warnings.warn("It seems that the points are not in the same space!")
+        return None
+    if len(ptsA) in (2, 3):
+        return float(np.sqrt(sum((float(a) - float(b)) ** 2 for a, b in zip(ptsA, ptsB))))
+    return None
+
+
 def return_list_of_vectors(tensor, by_row=True):
     """SIA:191-201."""
     if isinstance(tensor, dict):
