@@ -41,6 +41,12 @@ namespace ta {
 #ifndef TA_HOT_ADJ
 #define TA_HOT_ADJ 1
 #endif
+#ifndef TA_FACE_COMBINE
+#define TA_FACE_COMBINE 0   // 1: the top-of-plane face drains add equal consecutive records as one (segment heads only) -- measured: no gain
+#endif
+#ifndef TA_LSUM_REP
+#define TA_LSUM_REP 1    // 2: two replicas of a label slot's sums in the kernels with eight voxels a lane, by row parity -- measured: slower
+#endif
 #ifndef TA_FCAP
 #define TA_FCAP 192
 #endif
@@ -61,10 +67,14 @@ struct __attribute__((aligned(16))) ScanWaveLds {
     uint32_t cql[RCAP + 2], cqc[RCAP + 2];              // runs; record i lives in slot i + 1, slot 0 = sentinel / carry, slot RCAP + 1 = trash
 };
 
-template <int NW, bool ADJ>
+// NW packed words of sums per label slot and replica (SumPack); REP_ replicas of every slot: the runs of one label in a group of
+// 64 records come from consecutive rows, and rows of different parity add into different replicas (drain_run_group)
+template <int NW, bool ADJ, int REP_, typename PACK>
 struct __attribute__((aligned(16))) ScanLds {
+    static constexpr int REP = REP_;
+    using Pack = PACK;
     ScanWaveLds<ADJ> wave[WAVES];
-    uint64_t lsum[LSLOTS * NW];
+    uint64_t lsum[LSLOTS * NW * REP_];
     uint64_t pkeys[ADJ ? PSLOTS : 2];
 #if TA_PCNT64
     uint64_t pcnt[ADJ ? PSLOTS : 1];  // three 21-bit face counts per pair (PCNT_BITS)
@@ -170,6 +180,26 @@ __device__ __forceinline__ const SweepArgs* cold_args(const SweepArgs* kp) {
     return kp;
 }
 
+// ... and where MANY of them are needed -- the flush -- the whole argument block is fetched once through the CONSTANT address
+// space: a handful of s_load_dwordx4 into SGPRs.  (Through the generic pointer every field access is a per-lane FLAT load, a
+// vector-memory round trip the wave waits for; the flush re-read the pair table's pointers and mask that way inside its probe
+// loop and spent 9 % (C4) to 18 % (tissue everywhere) of a workgroup's life: profiles/NOTES.md, round 5.)
+struct KernelArgs { SweepArgs a; uint32_t split[6]; uint32_t wg0; };      // the kernarg segment of every sweep kernel: (SweepArgs, ScanSplit, uint32_t)
+__device__ __forceinline__ KernelArgs scalar_args(const SweepArgs* kp) {
+    typedef const __attribute__((address_space(4))) uint32_t* cu32;
+    static_assert(sizeof(SweepArgs) % 4 == 0, "(SweepArgs, ScanSplit of six words, uint32_t) back to back in the kernarg segment");
+    const cu32 w = (cu32)(uintptr_t)cold_args(kp);
+    KernelArgs k;
+    uint32_t buf[(sizeof(SweepArgs) + 28) / 4];
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(buf) / 4); ++i) buf[i] = w[i];
+    __builtin_memcpy(&k.a, buf, sizeof(SweepArgs));
+#pragma unroll
+    for (int i = 0; i < 6; ++i) k.split[i] = buf[sizeof(SweepArgs) / 4 + i];
+    k.wg0 = buf[sizeof(SweepArgs) / 4 + 6];
+    return k;
+}
+
 __device__ __forceinline__ const SweepArgs* kernarg_args(const SweepArgs& by_value) {
 #if defined(__HIP_DEVICE_COMPILE__)
     (void)by_value;        // the struct is the first (only explicit) kernel argument: it sits at offset 0 of the segment
@@ -202,7 +232,7 @@ template <bool MOM2, typename LDS, typename SUMS>
 __device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S,
                                                uint32_t label, const SUMS& L, uint32_t mna, uint32_t mxa, uint32_t mnb,
                                                uint32_t mxb, uint32_t mnc, uint32_t mxc, uint32_t h, uint32_t k) {
-    constexpr int NW = MOM2 ? 6 : 2;
+    constexpr int NW = MOM2 ? 4 : 2;
     int slot = -1;
 #pragma nounroll
     for (int probe = 0; probe < LPROBE; ++probe) {
@@ -215,21 +245,13 @@ __device__ __forceinline__ void scan_label_add(const SweepArgs* kp, LDS& S,
         k = S.lkeys[h];
     }
     if (slot >= 0) {
-        unsigned long long* row = (unsigned long long*)&S.lsum[slot * NW];
+        unsigned long long* row = (unsigned long long*)&S.lsum[slot * NW * LDS::REP];      // (replica 0)
+        uint64_t w[4];
+        LDS::Pack::template pack<MOM2>(L, w);
 #ifndef TA_ABL_NOSUMS          // (ablations: results wrong by construction, only the time matters)
-        atomicAdd(row + 0, (unsigned long long)((uint64_t)L.n | ((uint64_t)L.sb << 32)));
-        atomicAdd(row + 1, (unsigned long long)((uint64_t)L.sa | ((uint64_t)L.sc << 32)));
+#pragma unroll
+        for (int k = 0; k < NW; ++k) atomicAdd(row + k, (unsigned long long)w[k]);
 #endif
-#ifdef TA_ABL_NOSUMS
-        if (false) {
-#else
-        if (MOM2) {
-#endif
-            atomicAdd(row + 2, (unsigned long long)((uint64_t)L.saa | ((uint64_t)L.sab << 32)));
-            atomicAdd(row + 3, (unsigned long long)((uint64_t)L.sbb | ((uint64_t)L.sbc << 32)));
-            atomicAdd(row + (MOM2 ? 4 : 0), (unsigned long long)L.sac);
-            atomicAdd(row + (MOM2 ? 5 : 0), (unsigned long long)L.scc);
-        }
         // bounding box: read first, touch the atomics only when this contribution extends it
         uint32_t* box = &S.lbox[slot * 8];
         const uint4 cur = *reinterpret_cast<const uint4*>(box);          // min a,b,c | max a
@@ -520,12 +542,26 @@ __device__ __forceinline__ void drain_face_groups(const SweepArgs* kp, LDS& S, W
 #endif
 #pragma unroll
     for (int g = 0; g < NF; ++g) {
+        const bool ok = live[g] && !pend[g];
 #ifdef TA_ABL_SHARE1
-        if (TA_ABL_HOT < 1) { if (live[g] && !pend[g]) pcnt_add(S, (slot[g] + (uint32_t)lane * 7u) & (PSLOTS - 1), rec[g].y >> 30); }
+        if (TA_ABL_HOT < 1) { if (ok) pcnt_add(S, (slot[g] + (uint32_t)lane * 7u) & (PSLOTS - 1), rec[g].y >> 30); }
+#elif TA_FACE_COMBINE && !TA_PCNT64
+        // Records that follow each other in the buffer and are EQUAL -- a wall seen at consecutive columns, by consecutive
+        // positions of one lane -- are one segment: its first lane adds the segment's length, the others add nothing.  (An LDS
+        // atomic costs the CU ~7.7 cycles times the lanes of the instruction that share an address: a flat wall put 16+ of the
+        // 64 lanes on one counter.)  Equal records have equal keys, slots and states, so a segment is all `ok` or not at all.
+        if (TA_ABL_HOT < 1) {
+            const uint32_t px = lane_shr1(rec[g].x, ~rec[g].x), py = lane_shr1(rec[g].y, rec[g].y);      // (lane 0: never equal)
+            const bool same = ok && px == rec[g].x && py == rec[g].y;
+            const uint64_t cont = __builtin_amdgcn_ballot_w64(same);                 // lane j continues the segment of lane j - 1
+            const uint64_t after = ~((cont >> (uint32_t)lane) >> 1);                 // from lane + 1 on: the first 0 of `cont` ends it
+            const uint32_t len = 1u + (uint32_t)__builtin_ctzll(after);              // (the shifted-in zeros end every segment)
+            if (ok && !same) atomicAdd(&S.pcnt[slot[g] * 3u + (rec[g].y >> 30)], len);
+        }
 #else
-        if (TA_ABL_HOT < 1) { if (live[g] && !pend[g]) pcnt_add(S, slot[g], rec[g].y >> 30); }
+        if (TA_ABL_HOT < 1) { if (ok) pcnt_add(S, slot[g], rec[g].y >> 30); }
 #endif
-        else asm volatile("" :: "v"(slot[g]), "s"(__builtin_amdgcn_ballot_w64(live[g] && !pend[g])));
+        if (TA_ABL_HOT >= 1) asm volatile("" :: "v"(slot[g]), "s"(__builtin_amdgcn_ballot_w64(ok)));
         if (spill) {          // (wave-uniform: the probe limit was reached with lookups still open)
             if (pend[g]) { const SweepArgs* A = cold_args(kp); pair_spill_global(A->pairs, A->flags, lo[g], hi[g], rec[g].y >> 30, 1u); }
         }
@@ -539,7 +575,7 @@ template <bool MOM2, typename LDS, typename WLDS>
 __device__ __forceinline__ void drain_run_group(const SweepArgs* kp, LDS& S, WLDS& W, const bool EDGE, int lane, uint32_t& rcount,
                                                 const uint32_t lead_label) {
     static_assert(RCAP <= 128, "what is left after one group moves to the front one record per lane");
-    constexpr int NW = MOM2 ? 6 : 2;
+    constexpr int NW = MOM2 ? 4 : 2;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (TA_ABLATE >= 1) { rcount = 0u; return; }
 #ifdef TA_ABL_NOHOT
@@ -613,19 +649,18 @@ __device__ __forceinline__ void drain_run_group(const SweepArgs* kp, LDS& S, WLD
     const RunSums L = run_sums<MOM2>(c0, kk - c0, al, bl);
     if (TA_ABL_HOT >= 1) asm volatile("" :: "v"(L.n), "v"(L.sa), "v"(L.sb), "v"(L.sc), "v"(L.saa), "v"(L.sab), "v"(L.sac), "v"(L.sbb), "v"(L.sbc), "v"(L.scc), "v"(lslot), "s"(__builtin_amdgcn_ballot_w64(llive && !lpend)));
     if (TA_ABL_HOT < 1 && llive && !lpend) {
+        // (records of one label in a group come from consecutive rows: rows of different parity take different replicas, which
+        //  halves the lanes that share an address in each of these adds)
+        const uint32_t rep = LDS::REP > 1 ? (bl & (uint32_t)(LDS::REP - 1)) : 0u;
 #ifdef TA_ABL_SHARE1       // (ablation: every lane its own row -- no two lanes of an atomic share an address)
-        unsigned long long* row = (unsigned long long*)&S.lsum[((lslot + (uint32_t)lane) & (LSLOTS - 1)) * NW];
+        unsigned long long* row = (unsigned long long*)&S.lsum[((lslot + (uint32_t)lane) & (LSLOTS - 1)) * NW * LDS::REP];
 #else
-        unsigned long long* row = (unsigned long long*)&S.lsum[lslot * NW];
+        unsigned long long* row = (unsigned long long*)&S.lsum[(lslot * LDS::REP + rep) * NW];
 #endif
-        atomicAdd(row + 0, (unsigned long long)((uint64_t)L.n | ((uint64_t)L.sb << 32)));
-        atomicAdd(row + 1, (unsigned long long)((uint64_t)L.sa | ((uint64_t)L.sc << 32)));
-        if (MOM2) {
-            atomicAdd(row + 2, (unsigned long long)((uint64_t)L.saa | ((uint64_t)L.sab << 32)));
-            atomicAdd(row + 3, (unsigned long long)((uint64_t)L.sbb | ((uint64_t)L.sbc << 32)));
-            atomicAdd(row + (MOM2 ? 4 : 0), (unsigned long long)L.sac);
-            atomicAdd(row + (MOM2 ? 5 : 0), (unsigned long long)L.scc);
-        }
+        uint64_t w[4];
+        LDS::Pack::template pack<MOM2>(L, w);
+#pragma unroll
+        for (int k = 0; k < NW; ++k) atomicAdd(row + k, (unsigned long long)w[k]);
         // bounding box: touched only when this run extends it (almost every run lies inside the box its label already has)
 #ifdef TA_ABL_NOBOXHOT
         const bool grows = false;
@@ -771,9 +806,11 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 // left after a step, the next one's often do not fit and the whole buffer goes through the in-plane drain (29 % of C4's face
 // records, 43 % of the tissue-filled volume's, against 13 / 14 % with four voxels a lane).  With one group of 64 leaving at
 // the top of the plane those shares fall to 7 / 16 % -- and the sweep takes the same time (C4 1.01 / 1.02 vs 1.01 / 1.02 ms,
-// filled 1.38 - 1.44 vs 1.39 - 1.46, C5 6.79 / 6.83 vs 6.78 / 6.86): where a record is drained does not matter.  Off.
+// filled 1.38 - 1.44 vs 1.39 - 1.46, C5 6.79 / 6.83 vs 6.78 / 6.86): where a record is drained does not matter.  On since
+// round 5 (with the predicated stores: C4 0.972 -> 0.965, filled 1.392 -> 1.367 / 1.390 ms in one call -- within the noise, and
+// the in-plane drain with its per-lane probe loops becomes the rare path it is meant to be).
 #ifndef TA_FDRAIN1
-#define TA_FDRAIN1 0
+#define TA_FDRAIN1 1
 #endif
 #ifndef TA_FDRAIN
 #define TA_FDRAIN 128         // face records in the buffer from which the top-of-plane drain takes the full groups
@@ -924,6 +961,9 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     bool leading = true;
     uint32_t nlead = 0u;
     auto drain = [&](const bool may_keep) {
+#ifdef TA_ABL_NOSLOW      // (ablation, results wrong by construction: the in-plane drains and the end of the tile consume nothing)
+        fcount = 0u; rcount = 0u; if (lane == 0) W.cqc[0] = NO_ROW; return;
+#endif
 #ifdef TA_STAMPS
         const uint64_t td0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -1386,11 +1426,14 @@ __device__ __forceinline__ uint32_t claim_tile(uint32_t* queues, const uint32_t 
 // atomics are left in flight while the next tile starts, and no workgroup has to be launched (and waited out) per tile.
 template <typename T, int VPL, int RB, bool ADJ, bool MOM2, bool EDGE, int PINB, bool PERSIST = false, int PINB2 = 0>
 __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanSplit& sp, const uint32_t wg0) {
-    constexpr int NW = MOM2 ? 6 : 2;
+    constexpr int NW = MOM2 ? 4 : 2;
     constexpr int TC = 64 * VPL, TB = WAVES * RB;
     static_assert(TB <= 16 && TC <= 512, "packed LDS moment words assume <= 16 rows x 512 columns per tile");
     static_assert(!PERSIST || !EDGE, "the persistent kernel walks the full tiles");
-    using LDS = ScanLds<NW, ADJ>;
+    // two replicas of the label sums where the LDS has room at the kernel's occupancy (the tiles of eight voxels a lane: four
+    // workgroups a CU); the narrow uint32 tiles sit at five workgroups a CU and 31 KB, the moments-only kernels are not bound here
+    constexpr int REP = (ADJ && VPL == 8 && TA_LSUM_REP > 1) ? TA_LSUM_REP : 1;
+    using LDS = ScanLds<NW, ADJ, REP, SumPack<tile_planes_cap(ADJ, (int)sizeof(T), VPL), TB, TC>>;
     __shared__ LDS S;
     // the arguments only the cold paths need are re-read from the kernarg segment there (see cold_args)
     const SweepArgs* kp = kernarg_args(A);
@@ -1400,7 +1443,7 @@ __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanS
     for (int i = tid; i < LSLOTS; i += WAVES * 64) {
         S.lkeys[i] = INVALID_LABEL;
 #pragma unroll
-        for (int k = 0; k < NW; ++k) S.lsum[i * NW + k] = 0ull;
+        for (int k = 0; k < NW * REP; ++k) S.lsum[i * NW * REP + k] = 0ull;
         S.lbox[i * 8 + 0] = 0xFFFFFFFFu; S.lbox[i * 8 + 1] = 0xFFFFFFFFu; S.lbox[i * 8 + 2] = 0xFFFFFFFFu;
         S.lbox[i * 8 + 3] = 0u; S.lbox[i * 8 + 4] = 0u; S.lbox[i * 8 + 5] = 0u;
     }
@@ -1455,23 +1498,39 @@ __device__ __forceinline__ void scan_kernel_body(const SweepArgs& A, const ScanS
         if (tid == 0) { S.frame[0] = (uint32_t)A0; S.frame[1] = b_tile0; S.frame[2] = c_tile0; }
         __syncthreads();
 
+#ifdef TA_BARSTAMP       // (instrumentation: where a workgroup's life goes -- flags[8..12] = cycles >> 8 summed over the waves)
+        const uint64_t tb_start = __builtin_amdgcn_s_memtime();
+#endif
         if (p_lo < p_hi)
             wave_scan<T, VPL, RB, ADJ, MOM2, EDGE, PINB, PINB2>(A, kp, S, lane, w, c_tile0, b_tile0, p_lo, p_hi);
+#ifdef TA_BARSTAMP
+        const uint64_t tb_scan = __builtin_amdgcn_s_memtime();
+#endif
         __syncthreads();
+#ifdef TA_BARSTAMP
+        const uint64_t tb_bar = __builtin_amdgcn_s_memtime();
+#endif
         // (everything the flush needs is re-read -- arguments from the kernarg segment, the tile origin from LDS --
         //  rather than kept in scarce SGPRs across the sweep)
-        const SweepArgs& Ac = *cold_args(kp);
-        const uint32_t wg_ = reinterpret_cast<const uint32_t*>(&Ac + 1)[sizeof(ScanSplit) / 4] + tile;     // wg0 + tile
+        const KernelArgs ka = scalar_args(kp);
+        const SweepArgs& Ac = ka.a;
+        const uint32_t wg_ = ka.wg0 + tile;
         uint32_t next = NO_TILE;
-        if (PERSIST && tid == 0) {          // (asked for before the flush, needed after it)
-            const ScanSplit& spc = *reinterpret_cast<const ScanSplit*>(&Ac + 1);
-            next = claim_tile(Ac.flags + QUEUE_WORD, blockIdx.x & 7u, spc.fc * spc.fb * spc.nbands);
-        }
+        if (PERSIST && tid == 0)            // (asked for before the flush, needed after it; split: tiles_c, tiles_b, fc, fb, nbands, padded)
+            next = claim_tile(Ac.flags + QUEUE_WORD, blockIdx.x & 7u, ka.split[2] * ka.split[3] * ka.split[4]);
 #ifndef TA_ABL_NOFLUSH
         flush_tables<NW, ADJ, MOM2, (TA_HOT_ADJ || !ADJ), LDS, WAVES * 64, PERSIST>(Ac, S, threadIdx.x, (uint64_t)S.frame[0], (uint64_t)S.frame[1], (uint64_t)S.frame[2],
                                           (TA_HOT_ADJ || !ADJ) ? hot_label_of<T>(Ac) : 0u, wg_);
 #else
         if (wg_ == 0xffffffffu) S.frame[3] = 1;
+#endif
+#ifdef TA_BARSTAMP
+        if (lane == 0) {
+            uint32_t* fl = cold_args(kp)->flags;
+            const uint64_t tb_end = __builtin_amdgcn_s_memtime();
+            atomicAdd(&fl[8], (uint32_t)((tb_scan - tb_start) >> 8)); atomicAdd(&fl[9], (uint32_t)((tb_bar - tb_scan) >> 8));
+            atomicAdd(&fl[10], (uint32_t)((tb_end - tb_bar) >> 8)); atomicAdd(&fl[11], 1u);
+        }
 #endif
         if (!PERSIST) break;
         __syncthreads();                     // (the tile origin has been read by every thread's flush)
@@ -1591,7 +1650,13 @@ uint64_t sweep_grid_size(const SweepArgs& a, int itemsize, bool adjacency) {
 // (The wide uint32 tiles -- 8 rows x 512 columns -- hold twice the voxels a plane: 32 planes measure best on C4 and C5, and at
 //  48 the tissue-filled volume overflows the workgroup tables.)
 int sweep_default_tile_planes(bool adjacency, int itemsize, int shape) { return adjacency ? (itemsize == 4 ? (shape ? 32 : 48) : 32) : 16; }
-int sweep_max_tile_planes() { return MAX_TILE_PLANES; }
+int sweep_tile_planes_limit() { return MAX_TILE_PLANES; }
+// the tile height a kernel's packed sums are sized for (SumPack; results do not depend on the tile height)
+int sweep_max_tile_planes(bool adjacency, int itemsize, int shape) {
+    const int vpl = adjacency ? (itemsize == 2 ? VPL16_ADJ : (shape ? 8 : 4)) : (itemsize == 2 ? 8 : 4);
+    const int cap = tile_planes_cap(adjacency, itemsize, vpl);
+    return cap < MAX_TILE_PLANES ? cap : MAX_TILE_PLANES;
+}
 
 void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t feature_mask, hipEvent_t ev_start, hipEvent_t ev_stop) {
     const bool adj = feature_mask & 16u, mom2 = feature_mask & 8u;

@@ -252,7 +252,10 @@ int run_extract(ta_ctx* c) {
         // then spill to global atomics, ~100x dearer) get shorter tiles still: see finish_extract
         for (int k = 0; k < c->auto_tile_shift && a.tile_planes > 1; ++k) a.tile_planes /= 2;
     }
-    if (a.tile_planes > ta::sweep_max_tile_planes()) a.tile_planes = ta::sweep_max_tile_planes();   // packed LDS moment words
+    {   // packed LDS moment words: each kernel is built for tiles up to this height
+        const int cap = ta::sweep_max_tile_planes(c->feature_mask & TA_F_ADJACENCY, c->itemsize, a.shape);
+        if (a.tile_planes > cap) a.tile_planes = cap;
+    }
     // 16-byte loads: rows that are 16-byte aligned, or ANY rows of a volume the library uploaded itself (unaligned 16-byte
     // global loads are legal on gfx950 -- 6.2 TB/s from dword-aligned, 4.8 TB/s from odd addresses, measured -- and the
     // strip that straddles the end of the very last row reads into the slack ta_volume_set leaves behind the buffer)
@@ -472,7 +475,7 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
             if (value < 0 || value > 1) return fail(TA_EINVAL, "TA_OPT_IMPL must be 0 (sweep) or 1 (per-voxel atomics)");
             c->impl = (int)value; return TA_OK;
         case TA_OPT_TILE_PLANES:
-            if (value < 0 || value > ta::sweep_max_tile_planes()) return fail(TA_EINVAL, "TA_OPT_TILE_PLANES must be in [0,%d]", ta::sweep_max_tile_planes());
+            if (value < 0 || value > ta::sweep_tile_planes_limit()) return fail(TA_EINVAL, "TA_OPT_TILE_PLANES must be in [0,%d]", ta::sweep_tile_planes_limit());
             c->tile_planes = (int)value; return TA_OK;
         case TA_OPT_PAIR_SLOTS:
             if (value != 0 && (value < 4 || value > 30)) return fail(TA_EINVAL, "TA_OPT_PAIR_SLOTS must be 0 or in [4,30]");

@@ -106,6 +106,7 @@ void launch_scan(hipStream_t s, const SweepArgs& a, int itemsize, uint32_t featu
                  hipEvent_t ev_stop = nullptr);
 uint64_t sweep_grid_size(const SweepArgs& a, int itemsize, bool adjacency);   // workgroups of the sweep kernels of that feature class
 int sweep_default_tile_planes(bool adjacency, int itemsize, int shape);
-int sweep_max_tile_planes();
+int sweep_max_tile_planes(bool adjacency, int itemsize, int shape);   // what the kernel for these volumes packs its tile sums for
+int sweep_tile_planes_limit();                                        // what TA_OPT_TILE_PLANES accepts (taller than a kernel's cap: clamped)
 
 }  // namespace ta

@@ -58,6 +58,56 @@ struct LocalSums { uint64_t n, sa, sb, sc, saa, sab, sac, sbb, sbc, scc; };
 // one run's contribution: every term fits 32 bits (n <= 64, a < 64, b < 16, c < 512)
 struct RunSums { uint32_t n, sa, sb, sc, saa, sab, sac, sbb, sbc, scc; };
 
+// ---- the ten tile-local sums of a label slot, PACKED into four u64 words (two without second moments) --------------------
+// An LDS atomic costs the CU's one LDS pipe ~15 cycles (u64; ~7.7 for u32) times the number of lanes of the instruction that
+// share its address (scripts/pipes_bench.hip, profiles/r05_pipes.txt), and a group of 64 run records holds each label about
+// 3.5 times: the six u64 adds of a run were the largest single item of LDS time in tissue.  The bounds of a tile are known at
+// compile time -- P planes, B rows, C columns, every coordinate tile-local -- so every sum gets exactly the bits its largest
+// possible value takes, and the ten fit four words:   w0 = cc | bc,   w1 = ac | aa,   w2 = c | a | n,   w3 = ab | bb | b.
+// (All contributions are non-negative and the totals of a tile stay inside their fields: no field ever carries into the next.)
+template <int P, int B, int C>
+struct SumPack {
+    static constexpr uint64_t tri(uint64_t n) { return n * (n - 1) / 2; }                      // sum of i, i < n
+    static constexpr uint64_t sq(uint64_t n) { return (n - 1) * n * (2 * n - 1) / 6; }         // sum of i^2, i < n
+    static constexpr int bits(uint64_t x) { int b = 0; while (x) { ++b; x >>= 1; } return b; }
+    static constexpr int bN = bits((uint64_t)P * B * C);
+    static constexpr int bA = bits((uint64_t)B * C * tri(P)), bB = bits((uint64_t)P * C * tri(B)), bC = bits((uint64_t)P * B * tri(C));
+    static constexpr int bAA = bits((uint64_t)B * C * sq(P)), bAB = bits((uint64_t)C * tri(P) * tri(B)), bAC = bits((uint64_t)B * tri(P) * tri(C));
+    static constexpr int bBB = bits((uint64_t)P * C * sq(B)), bBC = bits((uint64_t)P * tri(B) * tri(C)), bCC = bits((uint64_t)P * B * sq(C));
+    static_assert(bCC + bBC <= 64 && bAC + bAA <= 64 && bC + bA + bN <= 64 && bAB + bBB + bB <= 64,
+                  "the tile is too large for four packed words: lower the kernel's cap on the tile height (tile_planes_cap)");
+    static constexpr int planes = P;
+    static constexpr uint64_t mask(int b) { return b >= 64 ? ~0ull : ((1ull << b) - 1ull); }
+    // MOM2: four words; else two: w0 = n | b << 32, w1 = a | c << 32 (every sum of a tile is below 2^32 there)
+    template <bool MOM2, typename SUMS>
+    static __device__ __forceinline__ void pack(const SUMS& L, uint64_t (&w)[4]) {
+        if (MOM2) {
+            w[0] = (uint64_t)L.scc + ((uint64_t)L.sbc << bCC);
+            w[1] = (uint64_t)L.sac + ((uint64_t)L.saa << bAC);
+            w[2] = (uint64_t)L.sc + ((uint64_t)L.sa << bC) + ((uint64_t)L.n << (bC + bA));
+            w[3] = (uint64_t)L.sab + ((uint64_t)L.sbb << bAB) + ((uint64_t)L.sb << (bAB + bBB));
+        } else {
+            w[0] = (uint64_t)L.n | ((uint64_t)L.sb << 32);
+            w[1] = (uint64_t)L.sa | ((uint64_t)L.sc << 32);
+            w[2] = w[3] = 0ull;
+        }
+    }
+    // adds the words of one slot (one replica) to L
+    template <bool MOM2>
+    static __device__ __forceinline__ void unpack_add(const uint64_t* w, LocalSums& L) {
+        if (MOM2) {
+            L.scc += w[0] & mask(bCC); L.sbc += w[0] >> bCC;
+            L.sac += w[1] & mask(bAC); L.saa += w[1] >> bAC;
+            L.sc += w[2] & mask(bC); L.sa += (w[2] >> bC) & mask(bA); L.n += w[2] >> (bC + bA);
+            L.sab += w[3] & mask(bAB); L.sbb += (w[3] >> bAB) & mask(bBB); L.sb += w[3] >> (bAB + bBB);
+        } else {
+            L.n += w[0] & 0xffffffffull; L.sb += w[0] >> 32; L.sa += w[1] & 0xffffffffull; L.sc += w[1] >> 32;
+        }
+    }
+};
+// the tallest tile each kind of sweep kernel packs its sums for (launches clamp the tile height to it; results never depend on it)
+constexpr int tile_planes_cap(bool adjacency, int itemsize, int vpl) { (void)itemsize; return adjacency ? (vpl == 4 ? 48 : 32) : 16; }
+
 // shift tile-local sums to global coordinates (origin A0,B0,C0): exact u64
 __device__ __forceinline__ void local_to_global(const LocalSums& L, uint64_t A0, uint64_t B0, uint64_t C0,
                                                 uint64_t (&g)[NSUM]) {
@@ -200,23 +250,21 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
 #endif
         const int i = llist[j];
         const uint32_t label = S.lkeys[i];
-        const uint64_t w0 = S.lsum[i * NW + 0], w1 = S.lsum[i * NW + 1];
         LocalSums L;
-        L.n = w0 & 0xffffffffull; L.sb = w0 >> 32; L.sa = w1 & 0xffffffffull; L.sc = w1 >> 32;
-        if (MOM2) {
-            const uint64_t w2 = S.lsum[i * NW + (MOM2 ? 2 : 0)], w3 = S.lsum[i * NW + (MOM2 ? 3 : 0)];
-            L.saa = w2 & 0xffffffffull; L.sab = w2 >> 32;
-            L.sbb = w3 & 0xffffffffull; L.sbc = w3 >> 32;
-            L.sac = S.lsum[i * NW + (MOM2 ? 4 : 0)]; L.scc = S.lsum[i * NW + (MOM2 ? 5 : 0)];
-        } else {
-            L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
+        L.n = L.sa = L.sb = L.sc = L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
+#pragma unroll
+        for (int rp = 0; rp < LDS::REP; ++rp) {            // (the replicas a label's runs were spread over: see drain_run_group)
+            uint64_t w[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+            for (int k = 0; k < NW; ++k) w[k] = S.lsum[(i * LDS::REP + rp) * NW + k];
+            LDS::Pack::template unpack_add<MOM2>(w, L);
         }
         const uint32_t bx0 = S.lbox[i * 8 + 0], bx1 = S.lbox[i * 8 + 1], bx2 = S.lbox[i * 8 + 2];
         const uint32_t bx3 = S.lbox[i * 8 + 3], bx4 = S.lbox[i * 8 + 4], bx5 = S.lbox[i * 8 + 5];
         if (RESET) {
             S.lkeys[i] = INVALID_LABEL;
 #pragma unroll
-            for (int k = 0; k < NW; ++k) S.lsum[i * NW + k] = 0ull;
+            for (int k = 0; k < NW * LDS::REP; ++k) S.lsum[i * NW * LDS::REP + k] = 0ull;
             S.lbox[i * 8 + 0] = 0xFFFFFFFFu; S.lbox[i * 8 + 1] = 0xFFFFFFFFu; S.lbox[i * 8 + 2] = 0xFFFFFFFFu;
             S.lbox[i * 8 + 3] = 0u; S.lbox[i * 8 + 4] = 0u; S.lbox[i * 8 + 5] = 0u;
         }
