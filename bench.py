@@ -77,6 +77,28 @@ def cpu_baseline(vol_tensor, dims, dtype, edge=400):
                 host_cpus=os.cpu_count())
 
 
+def pmc_traffic(config_name, kernel_name):
+    """HBM bytes per launch of THIS kernel on THIS config from profiles/pmc_traffic.json (separate rocprofv3 --pmc passes,
+    scripts/update_pmc_traffic.py) -- or None with the reason: no entry for the kernel that ran, or an entry measured on other
+    sources than the ones this run was built from (the hash of kernels_scan.hip + its headers travels with every entry)."""
+    import hashlib
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        db = json.load(open(path))
+        e = db.get("entries", {}).get(config_name, {}).get(kernel_name)
+        if e is None:
+            return None, "no PMC entry for %s on %s" % (kernel_name, config_name)
+        h = hashlib.sha256()
+        for f in ("tissue_analysis_amd/csrc/kernels_scan.hip", "tissue_analysis_amd/csrc/ta_sweep_common.h",
+                  "tissue_analysis_amd/csrc/ta_pin_tables.inc"):
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        if h.hexdigest()[:16] != e.get("sources_sha16"):
+            return None, "the PMC entry for %s (commit %s) was taken on other sweep sources" % (kernel_name, e.get("commit"))
+        return int(e["bytes"]), "PMC passes of commit %s (%s)" % (e.get("commit"), e.get("from"))
+    except Exception as exc:
+        return None, "pmc_traffic.json unreadable: %s" % type(exc).__name__
+
+
 def _slab_worker(args):
     """Best-effort CPU: one Z-slab of the sample through the one-pass C restatement (own process: it keeps globals)."""
     from oracle import onepass_c
@@ -326,13 +348,9 @@ def main():
         owned = job.owned_view()
         probe_ms = last_ctx().read_probe(owned.data_ptr(), owned.numel() * owned.element_size(), repeats=5)
         peak_measured = owned.numel() * owned.element_size() / (probe_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(cfg["name"])
-            except Exception:
-                traffic = None
+        kernel_name = ((("scan_wide_kernel" if last_ctx().get_option(_capi.OPT_SWEEP_SHAPE_USED) else "scan_two_rows_kernel")
+                        if dtype.itemsize == 4 else "scan_kernel") if feats & _capi.F_ADJACENCY else "scan_noadj_kernel")
+        traffic, traffic_note = pmc_traffic(cfg["name"], kernel_name)
         out = {
             "metric": "Mvoxels/s full-feature extraction, 1024^3 vol/50k labels; % HBM roofline",
             "value": round(value, 1), "unit": "Mvoxels/s", "n_gpus": n, "steps": args.steps,
@@ -352,9 +370,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "peak_measured": round(peak_measured, 1), "frac_of_measured": round(achieved / peak_measured, 4),
-                         "kernel": (("scan_wide_kernel" if last_ctx().get_option(_capi.OPT_SWEEP_SHAPE_USED) else "scan_two_rows_kernel")
-                                    if dtype.itemsize == 4 else "scan_kernel") if feats & _capi.F_ADJACENCY
-                                   else "scan_noadj_kernel",
+                         "traffic_note": traffic_note, "kernel": kernel_name,
                          "kernel_ms": round(sweep, 4), "kernel_launches_timed": len(sweep_ms),
                          "adjacency_collect_ms": round(float(np.mean(adj_ms)), 4),
                          "algorithmic_bytes_per_launch": int(bytes_read)},

@@ -35,8 +35,10 @@ extern "C" {
  *    TA_OPT_IMPL is 0 or 1; ta_adjacency_scope added; ta_timing answers zeros when no events were recorded.
  * 3: ta_volume_plane_events, ta_wall_medians(_get); ta_timing answers NaN for what was not measured.
  * 4: sparse label ids: ta_volume_label_census, ta_label_census_get, ta_volume_compact_labels, ta_volume_is_compact.
+ * 5: ta_volume_rerank, ta_volume_uncompact, ta_volume_owned_planes; ta_wall_medians marks a wall that did not settle (bit 31 of its
+ *    size word) instead of failing the call; TA_OPT_SWEEP_SHAPE -1 decides by label-change density, -2 by four timed sweeps.
  * A caller checks ta_version() == TA_ABI_VERSION of the header it was built against (the ctypes binding does). */
-#define TA_ABI_VERSION 4
+#define TA_ABI_VERSION 5
 
 #if defined(TA_BUILD)
 #define TA_API __attribute__((visibility("default")))
@@ -74,8 +76,10 @@ extern "C" {
                                * (eight voxels a lane, four waves per SIMD); 0: two rows of 256 (four voxels a lane, five waves).
                                * Same results; 1 is ~5 % faster on tissue with background around it, 0 on a volume that is cells
                                * everywhere, and on rows that are not whole 512-column tiles.  -1 (default): rows that are not take
-                               * 0; otherwise the first four sweeps of a volume take turns and the faster shape keeps the volume
-                               * (DESIGN.md §4.1). */
+                               * 0; otherwise decided BEFORE the volume's first sweep from the label changes per voxel in eight
+                               * sampled planes (above 0.032: shape 0) -- one small read-back, one stream synchronisation, once per
+                               * resident volume.  -2: the first four sweeps of a volume take turns between two events each and the
+                               * faster shape keeps the volume (round 4's rule). */
 #define TA_OPT_SWEEP_SHAPE_USED 8 /* read only: the shape the last sweep of this context ran with (0 where the shape does not apply) */
 #define TA_OPT_VOLUME_SLACK 6 /* bytes that are readable behind the volume adopted by ta_volume_set_device (reset to 0 by that
                                * call): with >= 16 the sweep uses 16-byte loads whatever the row length -- the strip that
@@ -138,6 +142,16 @@ TA_API int ta_volume_max_label(ta_ctx* ctx, uint32_t* max_label);
 TA_API int ta_volume_label_census(ta_ctx* ctx, uint32_t* max_label, uint32_t* n_present);
 TA_API int ta_label_census_get(ta_ctx* ctx, uint32_t* ids /* [n_present] */);
 TA_API int ta_volume_compact_labels(ta_ctx* ctx, const uint32_t* ids, uint32_t n_ids, uint32_t* n_rows);
+/* COMPACTION IS A SNAPSHOT OF THE VOXELS: the rank copy is written once, by ta_volume_compact_labels, and the sweep reads it from
+ * then on.  A caller that rewrites an adopted device buffer in place (the next frame of a time series, a refreshed halo plane)
+ * calls ta_volume_rerank before the next ta_extract: the same copy pass again, with the census the context already holds,
+ * asynchronous on the context's stream (~copy bandwidth: 1.7 ms for 1024^3 uint32).  An id the list does not hold makes the
+ * getters of the next extraction answer TA_ERANGE.  ta_volume_uncompact leaves the compacted state (dense rows 0 .. max_label
+ * again) and releases the rank copy.  New in TA_ABI_VERSION 5. */
+TA_API int ta_volume_rerank(ta_ctx* ctx);
+TA_API int ta_volume_uncompact(ta_ctx* ctx);
+/* planes along the slowest memory axis that this context owns (the halo plane excluded): the length of ta_volume_plane_events' output */
+TA_API int ta_volume_owned_planes(ta_ctx* ctx, int64_t* planes);
 TA_API int ta_volume_is_compact(ta_ctx* ctx, int* compact, uint32_t* n_rows);
 
 /* events[p] = label changes along memory axis 2 in OWNED plane p of the resident volume (one streaming pass; the halo
@@ -281,8 +295,10 @@ TA_API int ta_wall_voxels_get_by_pair(ta_ctx* ctx, uint32_t* pairs /* [n][2] */,
  * arithmetic of tissue_analysis_amd/geometry.py::weiszfeld_segments) on every wall -- one wave a wall --, truncates the
  * position and picks the wall voxel nearest to it (the first one on ties).  *nwalls = number of walls E; the results stay
  * on the context until the volume changes.  ta_wall_medians_get copies them out, sorted by (lo, hi): pairs u32[E][2], the
- * walls' voxel counts u32[E], the median voxels i32[E][3] in array-axis order.  TA_EINVAL when a wall is still moving after
- * max_iter passes (the reference raises there).  Volumes in memory (C) order only: the order of a wall's voxels decides ties. */
+ * walls' voxel counts u32[E], the median voxels i32[E][3] in array-axis order.  A wall that is still moving after max_iter
+ * passes (the reference raises there) is MARKED, not refused: bit 31 of its count word is set and its median is not to be
+ * used -- the caller raises for the walls it asked for (TA_ABI_VERSION 5; before, one such wall failed the whole call with
+ * TA_EINVAL).  Volumes in memory (C) order only (TA_EINVAL otherwise): the order of a wall's voxels decides ties. */
 TA_API int ta_wall_medians(ta_ctx* ctx, int max_iter, int64_t* nwalls, double* ms_kernels);
 TA_API int ta_wall_medians_get(ta_ctx* ctx, uint32_t* pairs, uint32_t* sizes, int32_t* medians);
 

@@ -18,7 +18,7 @@ from oracle import onepass, onepass_c          # noqa: E402  (the checker: this 
 def walk_c_abi():
     lib = _capi.load()
     assert os.path.samefile(_capi.LIB_PATH, os.environ["TISSUE_SCAN_LIB"])
-    assert lib.ta_version() == 4
+    assert lib.ta_version() == _capi.ABI_VERSION
     n = ctypes.c_int(-1)
     assert lib.ta_device_count(ctypes.byref(n)) in (_capi.TA_OK, _capi.TA_ENODEVICE)
     assert lib.ta_device_count(None) == _capi.TA_EINVAL
@@ -50,6 +50,9 @@ def walk_c_abi():
         "ta_label_census_get": (None, buf),
         "ta_volume_compact_labels": (None, None, 0, ctypes.byref(u32)),
         "ta_volume_is_compact": (None, ctypes.byref(ctypes.c_int(0)), None),
+        "ta_volume_rerank": (None,),
+        "ta_volume_uncompact": (None,),
+        "ta_volume_owned_planes": (None, ctypes.byref(i64)),
         "ta_volume_relabel": (None, buf, 4),
         "ta_volume_get": (None, buf),
         "ta_volume_map": (None, buf, 4, buf, 4, buf),

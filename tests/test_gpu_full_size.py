@@ -46,7 +46,7 @@ def test_c4_and_c3_full_size_against_the_c_oracle(capsys):
     ctx.set_option(_capi.OPT_SWEEP_SHAPE, 0)                        # ... and the narrow ones
     ctx.extract(_capi.F_ALL, L)
     got4n = fetch(ctx, L)
-    ctx.set_option(_capi.OPT_SWEEP_SHAPE, -1)                       # left to measure: the second sweep of a volume is a narrow one
+    ctx.set_option(_capi.OPT_SWEEP_SHAPE, -2)                       # four timed sweeps take turns: the second sweep of a volume is a narrow one
     c3 = _capi.feature_mask(synth.CONFIGS["C3"]["features"])
     ctx.extract(c3, L)
     ctx.extract(c3, L)
@@ -122,7 +122,7 @@ def test_c2_wall_medians_end_to_end_on_the_device(capsys):
     g = graph_from_image(sia, spatio_temporal_properties=['wall_median'], background=1, ignore_cells_at_stack_margins=False)
     t_dev = time.perf_counter() - t0
     assert sia._walls is None and sia._wall_medians
-    keys, sizes, med = sia._wall_medians
+    keys, sizes, med, _moving = sia._wall_medians
     kernels_ms = sia._resident().ms["wall_medians"]
     # a sample of the walls against the host arithmetic on the grouped records
     t0 = time.perf_counter()

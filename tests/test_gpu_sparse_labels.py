@@ -233,3 +233,57 @@ def test_the_analysis_class_end_to_end_on_ids_near_2_31():
     # the wall voxels and the voxel layers never see ranks
     la, lb = a.voxel_first_layer(), b.voxel_first_layer()
     assert np.array_equal(np.asarray(la), lut[np.asarray(lb)].astype(np.uint32))
+
+
+def test_compaction_is_a_snapshot_and_rerank_refreshes_it():
+    """a compacted context sweeps a rank copy written once.  An adopted device buffer rewritten in place is
+    seen again after ta_volume_rerank (SlabJob.refresh); an id outside the list raises at the next getter; ta_volume_uncompact
+    (extract_resident(sparse=False)) leaves the compacted state."""
+    import torch
+    from tissue_analysis_amd.extraction import extract_resident
+    a = voronoi((12, 16, 512), 20, 91, np.uint32).astype(np.int64)
+    ids = np.unique(a)
+    big = (ids * 1000003 + 7) % (2 ** 31)
+    order = np.argsort(big)
+    table = np.sort(big).astype(np.uint32)
+    lut = np.zeros(int(a.max()) + 1, dtype=np.uint32); lut[ids] = big.astype(np.uint32)
+    v1 = lut[a]                                               # sparse ids
+    t = torch.from_numpy(v1.view(np.int32)).cuda()
+    ctx = _capi.Context(0)
+    ctx.set_volume_device(t.data_ptr(), 4, t.shape, keep=t)
+    ctx.compact_labels(table)
+    ctx.extract(_capi.F_ALL, table.size - 1)
+    c1 = ctx.labels()[0]
+    # rewrite the buffer in place: swap two cells' ids everywhere
+    x, y = int(table[1]), int(table[2])
+    v2 = v1.copy(); v2[v1 == x] = y; v2[v1 == y] = x
+    t.copy_(torch.from_numpy(v2.view(np.int32)).cuda())
+    ctx.extract(_capi.F_ALL, table.size - 1)
+    assert np.array_equal(ctx.labels()[0], c1)                # stale by construction: the snapshot was swept
+    ctx.rerank()
+    ctx.extract(_capi.F_ALL, table.size - 1)
+    c2 = ctx.labels()[0]
+    assert c2[1] == c1[2] and c2[2] == c1[1] and np.array_equal(np.delete(c2, [1, 2]), np.delete(c1, [1, 2]))
+    # an id that is not in the list: the next getter raises
+    v3 = v2.copy(); v3[0, 0, 0] = int(table[-1]) + 5
+    t.copy_(torch.from_numpy(v3.view(np.int32)).cuda())
+    ctx.rerank()
+    ctx.extract(_capi.F_ALL, table.size - 1)
+    with pytest.raises(_capi.TissueScanError):
+        ctx.labels()
+    # leaving the compacted state
+    t.copy_(torch.from_numpy(a.astype(np.uint32).view(np.int32)).cuda())     # small ids again
+    assert ctx.is_compact()
+    x_dense = extract_resident(ctx, a.shape, _capi.F_ALL, sparse=False)
+    assert not ctx.is_compact() and x_dense.ids is None and int(x_dense.count.sum()) == a.size
+    ctx.close()
+
+
+def test_plane_events_length_with_a_size_one_axis():
+    """the slowest MEMORY axis is not argmax(strides) when an axis has size 1 (2-D images as (X, Y, 1))."""
+    a = voronoi((40, 48, 1), 12, 92, np.uint16, ellipsoid=False)
+    ctx = _capi.Context(0)
+    ctx.set_volume(a)
+    ev = ctx.plane_events()
+    assert ev.size == ctx.owned_planes() and int(ev.sum()) == int((a[:, 1:, 0] != a[:, :-1, 0]).sum())
+    ctx.close()

@@ -266,14 +266,51 @@ def test_both_tile_shapes_of_the_uint32_sweep_match_the_oracle(gpu_ctx, name, ma
 
 
 def test_the_measured_choice_of_the_shape_never_changes_the_result(gpu_ctx):
-    """Left to itself a context lets the first four sweeps of a volume take turns between the shapes and keeps the faster one:
-    eight sweeps of one resident volume, every one equal to the oracle."""
+    """TA_OPT_SWEEP_SHAPE = -2: the first four sweeps of a volume take turns between the shapes and the faster one keeps it:
+    eight sweeps of one resident volume, every one equal to the oracle; -1 (the default) decides before the first sweep."""
     vol = voronoi((24, 32, 1024), 80, 25, np.uint32)
     want = onepass_c.extract(vol)
-    gpu_ctx.set_volume(vol)
-    for k in range(8):
-        gpu_ctx.extract(_capi.F_ALL, int(vol.max()))
-        count, bbox, s1, s2 = gpu_ctx.labels()
-        lo, hi, f = gpu_ctx.adjacency()
-        got = dict(max_label=int(vol.max()), count=count, bbox=bbox, sum1=s1, sum2=s2, pair_lo=lo, pair_hi=hi, pair_faces=f)
-        assert_same_accumulators(got, want, "sweep %d" % k)
+    try:
+        for rule in (-2, -1):
+            gpu_ctx.set_option(_capi.OPT_SWEEP_SHAPE, rule)
+            gpu_ctx.set_volume(vol)
+            used = []
+            for k in range(8):
+                gpu_ctx.extract(_capi.F_ALL, int(vol.max()))
+                used.append(gpu_ctx.get_option(_capi.OPT_SWEEP_SHAPE_USED))
+                count, bbox, s1, s2 = gpu_ctx.labels()
+                lo, hi, f = gpu_ctx.adjacency()
+                got = dict(max_label=int(vol.max()), count=count, bbox=bbox, sum1=s1, sum2=s2, pair_lo=lo, pair_hi=hi, pair_faces=f)
+                assert_same_accumulators(got, want, "rule %d sweep %d" % (rule, k))
+            if rule == -2:
+                assert used[:4] == [1, 0, 1, 0] and len(set(used[4:])) == 1
+            else:
+                assert len(set(used)) == 1                     # one decision, before the first sweep
+    finally:
+        gpu_ctx.set_option(_capi.OPT_SWEEP_SHAPE, -1)
+
+
+def test_the_first_sweep_of_a_volume_already_runs_the_faster_shape():
+    """a caller that sweeps a volume ONCE (SpatialImageAnalysis(image)) must not get the un-tuned shape.  The
+    default rule looks at the label changes per voxel in eight sampled planes before the first sweep: tissue with background
+    around it (C4's cells inside the ellipsoid: 0.023 changes a voxel) takes the wide tiles, the same cells everywhere (0.054)
+    the narrow ones -- the shapes that are faster on C4 and on the tissue-filled C4 (profiles/NOTES.md, round 5)."""
+    import torch
+    from tissue_analysis_amd import device as dev, synth
+    c = synth.CONFIGS["C4"]
+    dims = (64, 256, 1024)
+    cells = max(8, c["n_cells"] * dims[0] * dims[1] * dims[2] // (1024 ** 3))
+    for ellipsoid, want_shape in ((True, 1), (False, 0)):
+        ctx = dev.torch_context(0)
+        vol, L = dev.synth_slab(ctx, dims, np.dtype(np.uint32), cells, c["seed"], ellipsoid=ellipsoid)
+        torch.cuda.synchronize()
+        ctx.set_volume_device(vol.data_ptr(), 4, vol.shape, keep=vol)
+        ctx.extract(_capi.F_ALL, L)
+        ctx.synchronize()
+        assert ctx.get_option(_capi.OPT_SWEEP_SHAPE_USED) == want_shape, "ellipsoid=%s" % ellipsoid
+        ctx.close()
+    # ... and through the class: one construction, one sweep, the narrow shape on dense tissue
+    from tissue_analysis_amd import DICT, SpatialImageAnalysis
+    img = voronoi((48, 64, 512), 400, 31, np.uint32, ellipsoid=False)
+    sia = SpatialImageAnalysis(img, ignoredlabels=0, return_type=DICT, background=1)
+    assert sia._resident().ctx.get_option(_capi.OPT_SWEEP_SHAPE_USED) == 0

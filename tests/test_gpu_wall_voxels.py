@@ -159,7 +159,8 @@ def test_wall_medians_on_the_device_equal_the_host_arithmetic(gpu_ctx, make):
     from tissue_analysis_amd import geometry
     vol = make()
     gpu_ctx.set_volume(vol)
-    keys, sizes, med, ms = gpu_ctx.wall_medians()
+    keys, sizes, med, ms, moving = gpu_ctx.wall_medians()
+    assert not moving.any()
     lo, hi, coords, _ = gpu_ctx.wall_voxels(by_pair=True)
     k = (lo.astype(np.uint64) << np.uint64(32)) | hi.astype(np.uint64)
     uk, first, count = np.unique(k, return_index=True, return_counts=True)
@@ -184,3 +185,23 @@ def test_graph_wall_medians_take_the_device_path():
     assert len(a) > 20 and dict(a.items()) == dict(b.items())
     for name in ('epidermis_wall_median', 'unlabelled_wall_median'):
         assert dict(g.vertex_property(name).items()) == dict(g2.vertex_property(name).items())
+
+
+def test_a_wall_that_does_not_settle_is_marked_and_only_raises_when_asked_for(gpu_ctx):
+    """One Weiszfeld pass is never enough (the stopping rule needs five): every wall comes back MARKED instead of the call
+    failing, and the class raises -- like the reference, SIA:1630-1633 -- only for a wall that is asked for."""
+    from tissue_analysis_amd import SpatialImageAnalysis3D
+    vol = voronoi((20, 24, 28), 12, 75, np.uint16)
+    gpu_ctx.set_volume(vol)
+    keys, sizes, med, ms, moving = gpu_ctx.wall_medians(max_iter=1)
+    assert keys.size > 5 and moving.all() and sizes.max() < 2 ** 31
+    keys2, sizes2, med2, _, moving2 = gpu_ctx.wall_medians()
+    assert not moving2.any() and np.array_equal(keys, keys2) and np.array_equal(sizes, sizes2)
+    sia = SpatialImageAnalysis3D(vol, ignoredlabels=0, background=1)
+    have, sz, m, mv = sia._resident().wall_medians()
+    mv = mv.copy(); mv[3] = True                                           # pretend wall 3 did not settle
+    sia._wall_medians = (have, sz, m, mv)
+    found, got = sia.wall_medians_of(have[[0, 1, 2]])                       # not asked for: no error
+    assert found.all() and np.array_equal(got, m[[0, 1, 2]])
+    with pytest.raises(ValueError):
+        sia.wall_medians_of(have[[2, 3]])

@@ -17,7 +17,7 @@ TA_OK, TA_EINVAL, TA_EHIP, TA_ENOMEM, TA_ERANGE, TA_ECAPACITY, TA_ENODEVICE = 0,
 F_VOLUME, F_BBOX, F_MOMENT1, F_MOMENT2, F_ADJACENCY = 1, 2, 4, 8, 16
 F_ALL = 31
 ADJ_LOCAL, ADJ_MERGED, ADJ_PARTIAL = 0, 1, 2
-ABI_VERSION = 4          # TA_ABI_VERSION of include/tissue_scan.h this binding was written against
+ABI_VERSION = 5          # TA_ABI_VERSION of include/tissue_scan.h this binding was written against
 FEATURES = dict(VOLUME=F_VOLUME, BBOX=F_BBOX, MOMENT1=F_MOMENT1, MOMENT2=F_MOMENT2,
                 ADJACENCY=F_ADJACENCY)
 OPT_IMPL, OPT_TILE_PLANES, OPT_PAIR_SLOTS, OPT_TIMING, OPT_TIMING_RING, OPT_VOLUME_SLACK, OPT_SWEEP_SHAPE, OPT_SWEEP_SHAPE_USED = 1, 2, 3, 4, 5, 6, 7, 8
@@ -28,7 +28,7 @@ SYMBOLS = (
     "ta_version", "ta_adjacency_scope", "ta_last_error", "ta_device_count", "ta_ctx_create", "ta_ctx_destroy",
     "ta_ctx_set_stream", "ta_ctx_set_option", "ta_ctx_get_option", "ta_ctx_synchronize", "ta_volume_set",
     "ta_volume_set_device", "ta_volume_max_label", "ta_volume_label_census", "ta_label_census_get", "ta_volume_compact_labels",
-    "ta_volume_is_compact", "ta_volume_plane_events", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
+    "ta_volume_is_compact", "ta_volume_rerank", "ta_volume_uncompact", "ta_volume_owned_planes", "ta_volume_plane_events", "ta_volume_relabel", "ta_volume_get", "ta_volume_map",
     "ta_volume_first_layer", "ta_volume_hollow", "ta_volume_layer18", "ta_wall_voxels_count", "ta_wall_voxels_get", "ta_wall_voxels_get_by_pair",
     "ta_wall_medians", "ta_wall_medians_get",
     "ta_extract", "ta_get_labels",
@@ -92,6 +92,9 @@ def load():
         "ta_label_census_get": (ci, [vp, vp]),
         "ta_volume_compact_labels": (ci, [vp, vp, u32, P(u32)]),
         "ta_volume_is_compact": (ci, [vp, P(ci), P(u32)]),
+        "ta_volume_rerank": (ci, [vp]),
+        "ta_volume_uncompact": (ci, [vp]),
+        "ta_volume_owned_planes": (ci, [vp, P(i64)]),
         "ta_volume_plane_events": (ci, [vp, vp]),
         "ta_volume_relabel": (ci, [vp, vp, u32]),
         "ta_volume_get": (ci, [vp, vp]),
@@ -313,24 +316,20 @@ class Context(object):
     def wall_medians(self, max_iter=200):
         """The median voxel of every wall of the resident volume, computed on the device (C-ordered volumes): keys
         uint64[E] = lo << 32 | hi ascending, sizes uint32[E] (wall voxels), medians int32[E, 3] (array-axis order), and
-        the kernels' milliseconds (grouping by pair included).  Raises ValueError where the reference does: a wall still
-        moving after `max_iter` Weiszfeld passes."""
+        the kernels' milliseconds (grouping by pair included) and `moving` bool[E]: walls whose iteration had not settled after
+        `max_iter` Weiszfeld passes (the reference raises for such a wall: the caller does, for the walls it asks for)."""
         n = ctypes.c_int64(0)
         _check(self._lib.ta_wall_voxels_count(self._h, ctypes.byref(n)))
         count, ms = ctypes.c_int64(0), ctypes.c_double(0.0)
-        try:
-            _check(self._lib.ta_wall_medians(self._h, int(max_iter), ctypes.byref(count), ctypes.byref(ms)))
-        except TissueScanError as e:
-            if e.code == TA_EINVAL and "still moving" in str(e):
-                raise ValueError(str(e))
-            raise
+        _check(self._lib.ta_wall_medians(self._h, int(max_iter), ctypes.byref(count), ctypes.byref(ms)))
         E = count.value
         pairs = np.empty((E, 2), dtype=np.uint32)
         sizes = np.empty(E, dtype=np.uint32)
         med = np.empty((E, 3), dtype=np.int32)
         _check(self._lib.ta_wall_medians_get(self._h, pairs.ctypes.data, sizes.ctypes.data, med.ctypes.data))
         keys = (pairs[:, 0].astype(np.uint64) << np.uint64(32)) | pairs[:, 1].astype(np.uint64)
-        return keys, sizes, med, ms.value
+        moving = (sizes & np.uint32(0x80000000)) != 0
+        return keys, sizes & np.uint32(0x7FFFFFFF), med, ms.value, moving
 
     def set_volume_device(self, dev_ptr, itemsize, buf_dims, a0_origin=0, has_low_halo=False, keep=None):
         _check(self._lib.ta_volume_set_device(self._h, ctypes.c_void_p(int(dev_ptr)), int(itemsize),
@@ -393,10 +392,24 @@ class Context(object):
         return out
 
     # -- hot path
+    def rerank(self):
+        """Compaction is a SNAPSHOT of the voxels: after rewriting an adopted device buffer in place, refresh the rank copy the
+        sweep reads (asynchronous; an id outside the census makes the next extraction's getters raise TA_ERANGE)."""
+        _check(self._lib.ta_volume_rerank(self._h))
+
+    def uncompact(self):
+        """Back to dense rows 0 .. max_label (releases the rank copy)."""
+        _check(self._lib.ta_volume_uncompact(self._h))
+
+    def owned_planes(self):
+        n = ctypes.c_int64(0)
+        _check(self._lib.ta_volume_owned_planes(self._h, ctypes.byref(n)))
+        return int(n.value)
+
     def plane_events(self):
         """uint64[owned planes]: label changes along the fast axis in every owned plane of the resident volume (the weight
         distributed.balanced_cuts balances)."""
-        out = np.zeros(self._owned_planes, dtype=np.uint64)
+        out = np.zeros(self.owned_planes(), dtype=np.uint64)      # (asked of the library: a size-1 axis moves the slowest MEMORY axis)
         _check(self._lib.ta_volume_plane_events(self._h, out.ctypes.data_as(ctypes.c_void_p)))
         return out
 

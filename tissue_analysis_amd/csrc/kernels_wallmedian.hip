@@ -93,7 +93,7 @@ __global__ void __launch_bounds__(64) wall_median_kernel(const uint2* pairs, con
         cost_2 = cost_1; cost_1 = cost;
         if (stop) { stopped = true; break; }
     }
-    if (!stopped && lane == 0) atomicOr(status, 1u);         // still moving after max_iter passes: the host raises
+    if (!stopped && lane == 0) atomicAdd(status, 1u);        // still moving after max_iter passes: counted, and marked in its size word
     // the wall voxel nearest to the truncated position, the first one on ties (a position that is not a number: the first voxel)
     const double o0 = trunc(y[0]), o1 = trunc(y[1]), o2 = trunc(y[2]);
     double best = INFINITY;
@@ -112,7 +112,7 @@ __global__ void __launch_bounds__(64) wall_median_kernel(const uint2* pairs, con
     }
     if (lane == 0) {
         out_pairs[w] = pairs[s];
-        out_sizes[w] = (uint32_t)m;
+        out_sizes[w] = (uint32_t)m | (stopped ? 0u : 0x80000000u);      // (bit 31: this wall's iteration did not settle)
         out_medians[3 * w] = P[3 * at]; out_medians[3 * w + 1] = P[3 * at + 1]; out_medians[3 * w + 2] = P[3 * at + 2];
     }
 }

@@ -96,6 +96,8 @@ struct ta_ctx {
     int64_t census_n = -1;              // ids present, -1 = no census
     int64_t vol_max = -1;               // largest label of the resident buffer (halo included), -1 = not known
     bool compact = false;               // per-label ROWS are ranks 0 .. census_n - 1; every label VALUE handed out is an id
+    bool census_of_volume = false;      // the census on the context was taken from THIS volume (not a caller's id list)
+    bool rerank_check = false;          // ta_volume_rerank's "id not in the list" word has not been looked at yet
     std::vector<uint32_t> h_ids;        // rank -> id (host copy, compact mode)
 
     // accumulators
@@ -132,7 +134,8 @@ struct ta_ctx {
     // is faster depends on the tissue (background around it: the wide one; cells everywhere: the narrow one), so the first four
     // sweeps of a volume take turns (wide, narrow, wide, narrow) between two events each, and the faster shape keeps the volume
     int opt_shape = -1;                                 // TA_OPT_SWEEP_SHAPE: -1 = measure, 0 / 1 = as told
-    int shape_pick = -1;                                // measured choice for this volume, -1 = not yet
+    int shape_pick = -1;                                // choice for this volume, -1 = not yet
+    double shape_density = -1.0;                        // label changes per voxel in the sampled planes (what decided it), -1 = not measured
     int last_shape = 0;                                 // TA_OPT_SWEEP_SHAPE_USED: the shape of the last sweep
     int tune_launched = 0;                              // measuring sweeps launched (0 .. 4)
     hipEvent_t tune_ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -164,6 +167,8 @@ const void* sweep_vol(const ta_ctx* c) { return c->compact ? c->compact_vol.p : 
 
 void drop_census(ta_ctx* c) {          // (whenever the voxels change)
     c->census_n = -1;
+    c->census_of_volume = false;
+    c->rerank_check = false;
     c->vol_max = -1;
     c->shape_pick = -1;
     c->tune_launched = 0;
@@ -204,6 +209,36 @@ int auto_pair_log2(uint32_t max_label) {
     return l;
 }
 
+// Label changes per voxel along the fast axis, from a SAMPLE of the owned planes (eight planes spread over the slab, one small
+// kernel each, one 64-byte read-back): what predicts which tile shape of the uint32 adjacency sweep is faster.  One stream
+// synchronisation, once per resident volume.  < 0: could not be measured.
+double sampled_event_density(ta_ctx* c) {
+    const int64_t owned = c->mdims[0] - c->first_owned;
+    if (owned <= 0 || c->mdims[1] <= 0 || c->mdims[2] <= 0 || !c->vol) return -1.0;
+    const int nsample = (int)std::min<int64_t>(8, owned);
+    DevBuf d;
+    if (d.reserve((uint64_t)nsample * sizeof(uint64_t)) != TA_OK) return -1.0;
+    const size_t plane_bytes = (size_t)c->mdims[1] * c->mdims[2] * c->itemsize;
+    for (int k = 0; k < nsample; ++k) {
+        const int64_t p = c->first_owned + ((2 * k + 1) * owned) / (2 * nsample);
+        ta::launch_plane_events(c->stream, (const char*)c->vol + (size_t)p * plane_bytes, c->itemsize, 1, c->mdims[1], c->mdims[2], (uint64_t*)d.p + k);
+    }
+    uint64_t ev[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipMemcpyAsync(ev, d.p, (size_t)nsample * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    d.release();
+    if (e != hipSuccess) { (void)hipGetLastError(); return -1.0; }
+    uint64_t tot = 0;
+    for (int k = 0; k < nsample; ++k) tot += ev[k];
+    return (double)tot / ((double)nsample * (double)c->mdims[1] * (double)c->mdims[2]);
+}
+
+// Above this many label changes per voxel the narrow tiles win (five waves a SIMD where every plane step is full of records),
+// below it the wide ones (fewer plane steps where most steps are background).  Same box, same call, round 5: C4 (0.023 changes a
+// voxel) wide 0.98 vs narrow 1.01 ms; the same cells without the ellipsoid (0.054) 1.38 vs 1.28 ms.
+constexpr double SHAPE_DENSITY_NARROW = 0.032;
+
 // The sweep shape of this launch; *tune = the measuring slot (0 .. 3) whose events bracket it, or -1.
 int sweep_shape(ta_ctx* c, bool adjacency, int* tune) {
     *tune = -1;
@@ -213,6 +248,16 @@ int sweep_shape(ta_ctx* c, bool adjacency, int* tune) {
     // against 1.05 ms), and a volume narrower than a tile has nothing else
     if (c->mdims[2] % 512 != 0) return 0;
     if (c->shape_pick >= 0) return c->shape_pick;
+    if (c->opt_shape == -1) {
+        // decided BEFORE the first sweep, from the density of label changes in a sample of planes (a caller that sweeps a volume
+        // once -- SpatialImageAnalysis(image) -- gets the faster shape on that sweep)
+        const double density = sampled_event_density(c);
+        c->shape_density = density;
+        c->shape_pick = (density >= 0.0 && density > SHAPE_DENSITY_NARROW) ? 0 : 1;
+        return c->shape_pick;
+    }
+    // TA_OPT_SWEEP_SHAPE = -2: the first four sweeps of the volume take turns (wide, narrow, wide, narrow), each between two
+    // events of its own, and the faster shape keeps the volume
     bool all = c->tune_launched == 4;
     for (int k = 0; k < c->tune_launched; ++k) {
         if (!c->tune_done[k]) {
@@ -227,7 +272,7 @@ int sweep_shape(ta_ctx* c, bool adjacency, int* tune) {
         return c->shape_pick;
     }
     if (c->tune_launched < 4 && c->tune_ev[7]) {
-        *tune = c->tune_launched++;
+        *tune = c->tune_launched;                     // (counted as launched by run_extract once BOTH its events are on the stream)
         return (*tune & 1) ^ 1;                       // wide, narrow, wide, narrow
     }
     return 1;                                         // (measured sweeps still in flight)
@@ -305,7 +350,10 @@ int run_extract(ta_ctx* c) {
     } else {
         ta::launch_scan(c->stream, a, c->itemsize, c->feature_mask, ev_a, ev_b);
     }
-    if (tune >= 0) TA_HIP(hipEventRecord(c->tune_ev[2 * tune + 1], c->stream));
+    if (tune >= 0) {
+        TA_HIP(hipEventRecord(c->tune_ev[2 * tune + 1], c->stream));
+        c->tune_launched = tune + 1;                  // (a slot counts only with both of its events recorded: an early return above leaves it to be measured again)
+    }
     // Without adjacency the LAST kernel of the step (the hot-row fold) mirrors the flag words into host-mapped memory
     // itself: no device-to-host copy (a blit kernel and a queue barrier) at the end of the step.  With adjacency the pair
     // count is final only when the collect kernel has ended; letting its last block publish it was measured and costs
@@ -329,6 +377,17 @@ int run_extract(ta_ctx* c) {
     return TA_OK;
 }
 
+// The word ta_volume_rerank writes shares its place with the max-label passes: whoever is about to reuse it looks at it first.
+int settle_rerank(ta_ctx* c) {
+    if (!c->rerank_check) return TA_OK;
+    uint32_t status = 0;
+    TA_HIP(hipMemcpyAsync(&status, maxlab_dev(c), sizeof(status), hipMemcpyDeviceToHost, c->stream));
+    TA_HIP(hipStreamSynchronize(c->stream));
+    c->rerank_check = false;
+    if (status) { c->extracted = false; return fail(TA_ERANGE, "the refreshed volume holds a label id that is not in the list the context was compacted with"); }
+    return TA_OK;
+}
+
 // Drain the stream and validate the flags of the last pass; grows the adjacency table and
 // re-runs when it overflowed.
 int finish_extract(ta_ctx* c) {
@@ -336,6 +395,10 @@ int finish_extract(ta_ctx* c) {
     if (c->checked) return TA_OK;
     if (c->exchanged) {       // the list came from other ranks too: a re-run is the host's call
         TA_HIP(hipStreamSynchronize(c->stream));
+        if (c->rerank_check) {
+            c->rerank_check = false;
+            if (c->h_small[ta::NFLAGS + 1]) { c->extracted = false; return fail(TA_ERANGE, "the refreshed volume holds a label id that is not in the list the context was compacted with"); }
+        }
         if (c->h_small[ta::FLAG_RANGE])
             return fail(TA_ERANGE, "a rank saw a label above max_label=%u", c->max_label);
         if (c->h_small[ta::FLAG_EXCHANGE_OVERFLOW])
@@ -348,6 +411,13 @@ int finish_extract(ta_ctx* c) {
     }
     for (int attempt = 0; attempt < 8; ++attempt) {
         TA_HIP(hipStreamSynchronize(c->stream));
+        if (c->rerank_check) {          // (the word ta_volume_rerank left behind came back with this extraction's flags)
+            c->rerank_check = false;
+            if (c->h_small[ta::NFLAGS + 1]) {
+                c->extracted = false;
+                return fail(TA_ERANGE, "the refreshed volume holds a label id that is not in the list the context was compacted with");
+            }
+        }
         if (c->h_small[ta::FLAG_RANGE])
             return fail(TA_ERANGE, "the volume holds a label above max_label=%u", c->max_label);
         if (!c->h_small[ta::FLAG_PAIR_OVERFLOW]) {
@@ -481,9 +551,12 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
             if (value != 0 && (value < 4 || value > 30)) return fail(TA_EINVAL, "TA_OPT_PAIR_SLOTS must be 0 or in [4,30]");
             c->opt_pair_log2 = (int)value; return TA_OK;
         case TA_OPT_SWEEP_SHAPE:
-            if (value < -1 || value > 1) return fail(TA_EINVAL, "TA_OPT_SWEEP_SHAPE is -1 (measure), 0 or 1");
+            if (value < -2 || value > 1) return fail(TA_EINVAL, "TA_OPT_SWEEP_SHAPE is -1 (by label-change density), -2 (by four timed sweeps), 0 or 1");
             c->opt_shape = (int)value;
             c->auto_tile_shift = 0;
+            c->shape_pick = -1;                    // (decided again, by the new rule, at the next sweep)
+            c->tune_launched = 0;
+            for (bool& d : c->tune_done) d = false;
             return TA_OK;
         case TA_OPT_VOLUME_SLACK:
             if (value < 0) return fail(TA_EINVAL, "TA_OPT_VOLUME_SLACK must be >= 0");
@@ -906,6 +979,9 @@ TA_API int ta_wall_medians(ta_ctx* c, int max_iter, int64_t* nwalls, double* ms_
     if (!c || !nwalls) return fail(TA_EINVAL, "NULL argument");
     if (c->wall_records < 0) return fail(TA_EINVAL, "call ta_wall_voxels_count first");
     if (max_iter < 1) return fail(TA_EINVAL, "max_iter must be positive");
+    if (c->perm[0] != 0 || c->perm[1] != 1 || c->perm[2] != 2)
+        return fail(TA_EINVAL, "wall medians need a C-ordered volume (the order of a wall's voxels decides ties)");
+    if ((uint64_t)c->wall_records >= (1ull << 31)) return fail(TA_EINVAL, "too many records for the wall medians");
     int rc = use_device(c);
     if (rc != TA_OK) return rc;
     const uint64_t n = (uint64_t)c->wall_records;
@@ -954,7 +1030,8 @@ TA_API int ta_wall_medians(ta_ctx* c, int max_iter, int64_t* nwalls, double* ms_
     buf.release(); scratch.release(); starts.release();
     if (rc != TA_OK) return rc;
     if (e != hipSuccess) return fail(TA_EHIP, "wall medians: %s", hipGetErrorString(e));
-    if (status) return fail(TA_EINVAL, "Weiszfeld iteration: a wall is still moving after %d passes", max_iter);
+    // (walls still moving after max_iter passes are MARKED -- bit 31 of their size word -- not refused: a caller asks for
+    //  some walls, and one that nobody asks for -- the background's, say -- must not fail the rest)
     c->wall_median_count = (int64_t)E;
     *nwalls = (int64_t)E;
     if (ms_out) *ms_out = ms;
@@ -992,6 +1069,7 @@ TA_API int ta_volume_max_label(ta_ctx* c, uint32_t* max_label) {
     int rc = use_device(c);
     if (rc != TA_OK) return rc;
     const uint64_t nvox = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2];
+    if ((rc = settle_rerank(c)) != TA_OK) return rc;
     ta::launch_max_label(c->stream, c->vol, c->itemsize, nvox, maxlab_dev(c));
     uint32_t v = 0;
     TA_HIP(hipMemcpyAsync(&v, maxlab_dev(c), sizeof(v), hipMemcpyDeviceToHost, c->stream));
@@ -1055,6 +1133,7 @@ int build_census(ta_ctx* c, const uint32_t* ids, uint32_t n_ids) {
     if (e != hipSuccess) return fail(TA_EHIP, "label census: %s", hipGetErrorString(e));
     c->census_max = top;
     c->census_n = (int64_t)total;
+    c->census_of_volume = ids == nullptr;
     return TA_OK;
 }
 }  // namespace
@@ -1088,8 +1167,9 @@ TA_API int ta_volume_compact_labels(ta_ctx* c, const uint32_t* ids, uint32_t n_i
     int rc = use_device(c);
     if (rc != TA_OK) return rc;
     c->compact = false;
+    c->rerank_check = false;
     c->extracted = c->checked = false;
-    if (ids || c->census_n < 0)
+    if (ids || c->census_n < 0 || !c->census_of_volume)          // (ids == NULL means THIS volume's census: never a caller's list left behind)
         if ((rc = build_census(c, ids, n_ids)) != TA_OK) return rc;
     if (c->census_n >= (1ll << 28)) return fail(TA_ERANGE, "%lld label ids are present: too many for per-label rows", (long long)c->census_n);
     const uint64_t nvox = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2];
@@ -1117,6 +1197,46 @@ TA_API int ta_volume_is_compact(ta_ctx* c, int* compact, uint32_t* n_rows) {
     if (!c || !compact) return fail(TA_EINVAL, "NULL argument");
     *compact = c->compact ? 1 : 0;
     if (n_rows) *n_rows = c->compact ? (uint32_t)c->census_n : 0u;
+    return TA_OK;
+}
+
+TA_API int ta_volume_rerank(ta_ctx* c) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if (!c->vol) return fail(TA_EINVAL, "no volume set");
+    if (!c->compact) return fail(TA_EINVAL, "the context is not compacted");
+    int rc = use_device(c);
+    if (rc != TA_OK) return rc;
+    const uint64_t nvox = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2];
+    c->extracted = c->checked = false;
+    // asynchronous on the context's stream: the "id not in the census" word travels to the host with the flags of the next
+    // extraction, whose getters then answer TA_ERANGE
+    hipError_t e = hipMemsetAsync(maxlab_dev(c), 0, sizeof(uint32_t), c->stream);
+    if (e == hipSuccess) {
+        ta::launch_census_rank(c->stream, c->vol, c->compact_vol.p, c->itemsize, nvox, c->census.p, c->census_max, maxlab_dev(c));
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) return fail(TA_EHIP, "re-rank: %s", hipGetErrorString(e));
+    c->rerank_check = true;
+    c->vol_max = -1;
+    return TA_OK;
+}
+
+TA_API int ta_volume_uncompact(ta_ctx* c) {
+    if (!c) return fail(TA_EINVAL, "ctx is NULL");
+    if (c->compact) {
+        if (c->stream) (void)hipStreamSynchronize(c->stream);
+        c->compact = false;
+        c->rerank_check = false;
+        c->extracted = c->checked = false;
+        c->compact_vol.release();
+        c->auto_tile_shift = 0;
+    }
+    return TA_OK;
+}
+
+TA_API int ta_volume_owned_planes(ta_ctx* c, int64_t* planes) {
+    if (!c || !planes) return fail(TA_EINVAL, "NULL argument");
+    *planes = c->vol ? c->mdims[0] - c->first_owned : 0;
     return TA_OK;
 }
 
@@ -1358,6 +1478,7 @@ TA_API int ta_read_probe(ta_ctx* c, const void* dev_ptr, uint64_t bytes, int rep
     if (repeats < 1) repeats = 1;
     int rc = use_device(c);
     if (rc != TA_OK) return rc;
+    if ((rc = settle_rerank(c)) != TA_OK) return rc;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     hipError_t e = hipEventCreate(&e0);
     if (e == hipSuccess) e = hipEventCreate(&e1);

@@ -267,6 +267,8 @@ class SlabJob(object):
         """ids: SPARSE label ids -- the ascending table of ALL ids of the partitioned volume (`union_of_ids`, the same on every
         rank): the slab is swept in the ranks of that table, every per-label row of this job (sums, boxes, the exchange) is a
         rank, `max_label` is ignored (rows = len(ids)) and result_arrays() answers pairs in ids and carries the table.
+        COMPACTION IS A SNAPSHOT: the context sweeps a rank copy of the slab written once, here.  After rewriting the adopted
+        buffer in place (the next frame of a series, a refreshed halo plane) call refresh() before the next step().
         reduce: "all" -- both tables all-reduced, every rank holds the global rows after step(); "scatter" -- the sums
         (8 of the 10.4 MB at 100k labels) are reduce-SCATTERED: a rank keeps the global rows of its share of the labels in
         `sums_shard` (and its own slab's partial rows in `sums`), only the boxes, which decide which pairs travel, are
@@ -418,6 +420,14 @@ class SlabJob(object):
     def _on_stream(self):
         import contextlib
         return self._torch.cuda.stream(self.stream) if self.stream is not None else contextlib.nullcontext()
+
+    def refresh(self):
+        """The voxels of the adopted buffer were rewritten in place: with `ids` the sweep reads a rank copy, which is written
+        again here (asynchronous, on the job's stream; an id outside `ids` makes the next finish() / getter raise TA_ERANGE).
+        Without `ids` the sweep reads the buffer itself and there is nothing to do."""
+        if self.ids is not None:
+            with self._on_stream():
+                self.ctx.rerank()
 
     def step(self):
         with self._on_stream():
@@ -583,6 +593,11 @@ class PipelinedSlabJob(object):
 
     def owned_view(self):
         return self.jobs[0].owned_view()
+
+    def refresh(self):
+        """The slab's voxels were rewritten in place: every job in flight re-reads them (see SlabJob.refresh)."""
+        for j in self.jobs:
+            j.refresh()
 
     def step(self):
         self.jobs[self._issued % len(self.jobs)].step()

@@ -412,8 +412,11 @@ def wants_compaction(max_label, n_present):
 def extract_resident(ctx, shape, features=_capi.F_ALL, max_label=None, sparse=None):
     """Run the sweep on the volume already resident in `ctx` and fetch the result.  sparse: None = decide from the volume
     (`wants_compaction`: one max-label pass, and a census of the ids when that is large), True / False = as told; an explicit
-    `max_label` means dense rows 0..max_label, as before."""
+    `max_label` means dense rows 0..max_label, as before.  A context left compacted by an earlier call stays compacted when
+    nothing else is asked for; `sparse=False` or an explicit `max_label` leave the compacted state first (dense rows it is)."""
     ids = None
+    if ctx.is_compact() and (sparse is False or max_label is not None):
+        ctx.uncompact()
     if ctx.is_compact():
         ids = ctx.compact_ids()
     elif max_label is None and sparse is not False:
@@ -513,14 +516,14 @@ class ResidentVolume(object):
         return WallTable(lo, hi, coords, ms)
 
     def wall_medians(self, max_iter=200):
-        """(keys uint64[E] ascending = lo << 32 | hi, sizes[E], medians int64[E, 3]) of every wall, computed on the device
+        """(keys uint64[E] ascending = lo << 32 | hi, sizes[E], medians int64[E, 3], moving bool[E]) of every wall, computed on the device
         from the records grouped by pair -- or None when the image is not C-ordered (the order of a wall's voxels decides
         ties: the caller then works from wall_table() on the host)."""
         if not self.host.flags.c_contiguous:
             return None
-        keys, sizes, med, ms = self.ctx.wall_medians(max_iter)
+        keys, sizes, med, ms, moving = self.ctx.wall_medians(max_iter)
         self.ms["wall_medians"] = ms
-        return keys, sizes, med.astype(np.int64)
+        return keys, sizes, med.astype(np.int64), moving
 
     def relabel(self, lut, features=_capi.F_ALL):
         """v -> lut[v] on the resident volume AND on `self.host` (copied back), then sweep the new volume."""

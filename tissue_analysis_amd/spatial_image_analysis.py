@@ -666,10 +666,13 @@ class AbstractSpatialImageAnalysis(object):
             self._wall_medians = self._resident().wall_medians() or False
         dev = getattr(self, "_wall_medians", None)
         if dev:
-            have, _sizes, med = dev
+            have, _sizes, med, moving = dev
             at = np.searchsorted(have, keys)
             found = at < have.size
             found[found] = have[at[found]] == keys[found]
+            if moving[at[found]].any():        # (raised for a wall that was ASKED for, like the reference: SIA:1630-1633)
+                k = int(keys[found][moving[at[found]]][0])
+                raise ValueError("Weiszfeld iteration: the wall (%d, %d) is still moving after the last pass" % (k >> 32, k & 0xFFFFFFFF))
             return found, med[at[found]]
         table = self.wall_table()
         at = np.searchsorted(table.pairs, keys)
