@@ -168,6 +168,53 @@ __device__ __forceinline__ void store_run_if_ne(uint32_t& off, const uint32_t v,
         asm volatile(TA_CMPX_PART("%2", "%3") "v_or_b32_e32 %1, %5, %4\n\tds_write2_b32 %0, %3, %1 offset1:%6\n\tv_add_u32_e32 %0, 4, %0\n\ts_mov_b64 exec, %7"
                      : "+v"(off), "=&v"(t) : "v"(v), "v"(pcv), "v"(code0), "n"(J), "n"(STRIDE), "s"(live) : "vcc", "memory");
 }
+// Four positions in ONE asm statement (between separate statements the compiler pads a wait state it cannot rule out: an s_nop per
+// position).  `EX`: what EXEC is put back to after each position.
+#define TA_FACE_POS(v, pv, EX) TA_CMPX(v, pv) "ds_write2_b32 %0, " v ", " pv " offset1:1\n\tv_add_u32_e32 %0, 8, %0\n\ts_mov_b64 exec, " EX "\n\t"
+#define TA_FACE_POS_PART(v, pv, EX) TA_CMPX_PART(v, pv) "ds_write2_b32 %0, " v ", " pv " offset1:1\n\tv_add_u32_e32 %0, 8, %0\n\ts_mov_b64 exec, " EX "\n\t"
+template <bool FULL>
+__device__ __forceinline__ void store_faces4_if_ne(uint32_t& off, const uint32_t v0, const uint32_t p0, const uint32_t v1, const uint32_t p1,
+                                                   const uint32_t v2, const uint32_t p2, const uint32_t v3, const uint32_t p3, const uint64_t live) {
+    if constexpr (FULL)
+        asm volatile(TA_FACE_POS("%1", "%2", "-1") TA_FACE_POS("%3", "%4", "-1") TA_FACE_POS("%5", "%6", "-1") TA_FACE_POS("%7", "%8", "-1")
+                     : "+v"(off) : "v"(v0), "v"(p0), "v"(v1), "v"(p1), "v"(v2), "v"(p2), "v"(v3), "v"(p3) : "vcc", "memory");
+    else
+        asm volatile(TA_FACE_POS_PART("%1", "%2", "%9") TA_FACE_POS_PART("%3", "%4", "%9") TA_FACE_POS_PART("%5", "%6", "%9") TA_FACE_POS_PART("%7", "%8", "%9")
+                     : "+v"(off) : "v"(v0), "v"(p0), "v"(v1), "v"(p1), "v"(v2), "v"(p2), "v"(v3), "v"(p3), "s"(live) : "vcc", "memory");
+}
+// ... the neighbour words tagged with the axis (%1: scratch, %10: the tag)
+#define TA_TFACE_POS(v, pv, EX) TA_CMPX(v, pv) "v_or_b32_e32 %1, %10, " pv "\n\tds_write2_b32 %0, " v ", %1 offset1:1\n\tv_add_u32_e32 %0, 8, %0\n\ts_mov_b64 exec, " EX "\n\t"
+#define TA_TFACE_POS_PART(v, pv, EX) TA_CMPX_PART(v, pv) "v_or_b32_e32 %1, %10, " pv "\n\tds_write2_b32 %0, " v ", %1 offset1:1\n\tv_add_u32_e32 %0, 8, %0\n\ts_mov_b64 exec, " EX "\n\t"
+template <bool FULL>
+__device__ __forceinline__ void store_faces4_tagged_if_ne(uint32_t& off, const uint32_t v0, const uint32_t p0, const uint32_t v1, const uint32_t p1,
+                                                          const uint32_t v2, const uint32_t p2, const uint32_t v3, const uint32_t p3,
+                                                          const uint32_t tag, const uint64_t live) {
+    uint32_t t;
+    if constexpr (FULL)
+        asm volatile(TA_TFACE_POS("%2", "%3", "-1") TA_TFACE_POS("%4", "%5", "-1") TA_TFACE_POS("%6", "%7", "-1") TA_TFACE_POS("%8", "%9", "-1")
+                     : "+v"(off), "=&v"(t) : "v"(v0), "v"(p0), "v"(v1), "v"(p1), "v"(v2), "v"(p2), "v"(v3), "v"(p3), "s"(tag) : "vcc", "memory");
+    else
+        asm volatile(TA_TFACE_POS_PART("%2", "%3", "%11") TA_TFACE_POS_PART("%4", "%5", "%11") TA_TFACE_POS_PART("%6", "%7", "%11") TA_TFACE_POS_PART("%8", "%9", "%11")
+                     : "+v"(off), "=&v"(t) : "v"(v0), "v"(p0), "v"(v1), "v"(p1), "v"(v2), "v"(p2), "v"(v3), "v"(p3), "s"(tag), "s"(live) : "vcc", "memory");
+}
+// ... four run records: positions J .. J + 3 of the strip; v_k against the voxel before it (p0 = the voxel left of v0); %1: scratch,
+// %7: code0, %8 .. %11: J .. J + 3, %12: the dword stride between the two run arrays
+#define TA_RUN_POS(v, pv, j, EX) TA_CMPX(v, pv) "v_or_b32_e32 %1, " j ", %7\n\tds_write2_b32 %0, " pv ", %1 offset1:%12\n\tv_add_u32_e32 %0, 4, %0\n\ts_mov_b64 exec, " EX "\n\t"
+#define TA_RUN_POS_PART(v, pv, j, EX) TA_CMPX_PART(v, pv) "v_or_b32_e32 %1, " j ", %7\n\tds_write2_b32 %0, " pv ", %1 offset1:%12\n\tv_add_u32_e32 %0, 4, %0\n\ts_mov_b64 exec, " EX "\n\t"
+template <bool FULL, int J, int STRIDE>
+__device__ __forceinline__ void store_runs4_if_ne(uint32_t& off, const uint32_t p0, const uint32_t v0, const uint32_t v1, const uint32_t v2, const uint32_t v3,
+                                                  const uint32_t code0, const uint64_t live) {
+    static_assert(STRIDE < 256, "ds_write2_b32 offsets are 8 bits of dwords");
+    uint32_t t;
+    if constexpr (FULL)
+        asm volatile(TA_RUN_POS("%3", "%2", "%8", "-1") TA_RUN_POS("%4", "%3", "%9", "-1") TA_RUN_POS("%5", "%4", "%10", "-1") TA_RUN_POS("%6", "%5", "%11", "-1")
+                     : "+v"(off), "=&v"(t) : "v"(p0), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(code0), "n"(J), "n"(J + 1), "n"(J + 2), "n"(J + 3), "n"(STRIDE)
+                     : "vcc", "memory");
+    else
+        asm volatile(TA_RUN_POS_PART("%3", "%2", "%8", "%13") TA_RUN_POS_PART("%4", "%3", "%9", "%13") TA_RUN_POS_PART("%5", "%4", "%10", "%13") TA_RUN_POS_PART("%6", "%5", "%11", "%13")
+                     : "+v"(off), "=&v"(t) : "v"(p0), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "v"(code0), "n"(J), "n"(J + 1), "n"(J + 2), "n"(J + 3), "n"(STRIDE), "s"(live)
+                     : "vcc", "memory");
+}
 // behind the last predicated store of a row: a DPP instruction needs five wait states after a VALU write of EXEC
 __device__ __forceinline__ void emit_done() { asm volatile("s_nop 4" ::: "memory"); }
 
@@ -1041,7 +1088,13 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 #pragma unroll
             for (int j = 0; j < VPL; ++j) {
 #if TA_MASKED_STORES & 1
-                store_face_if_ne<decltype(full)::value>(offf, cur[r][j], old[r][j], live);
+                if constexpr (VPL % 4 == 0) {
+                    if (j % 4 == 0)
+                        store_faces4_if_ne<decltype(full)::value>(offf, cur[r][j], old[r][j], cur[r][(j + 1) % VPL], old[r][(j + 1) % VPL],
+                                                                 cur[r][(j + 2) % VPL], old[r][(j + 2) % VPL], cur[r][(j + 3) % VPL], old[r][(j + 3) % VPL], live);
+                } else {
+                    store_face_if_ne<decltype(full)::value>(offf, cur[r][j], old[r][j], live);
+                }
                 continue;
 #endif
                 uint32_t v = cur[r][j];
@@ -1229,7 +1282,17 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                     {
                         const uint32_t pv = r > 0 ? cur[r > 0 ? r - 1 : 0][j] : up[j];
 #if TA_MASKED_STORES & 2
-                        store_face_tagged_if_ne<FULL>(offf, cur[r][j], pv, tag1, live);
+                        if constexpr (VPL % 4 == 0) {
+                            if (j % 4 == 0) {
+                                const uint32_t pv1 = r > 0 ? cur[r > 0 ? r - 1 : 0][(j + 1) % VPL] : up[(j + 1) % VPL];
+                                const uint32_t pv2 = r > 0 ? cur[r > 0 ? r - 1 : 0][(j + 2) % VPL] : up[(j + 2) % VPL];
+                                const uint32_t pv3 = r > 0 ? cur[r > 0 ? r - 1 : 0][(j + 3) % VPL] : up[(j + 3) % VPL];
+                                store_faces4_tagged_if_ne<FULL>(offf, cur[r][j], pv, cur[r][(j + 1) % VPL], pv1, cur[r][(j + 2) % VPL], pv2,
+                                                                cur[r][(j + 3) % VPL], pv3, tag1, live);
+                            }
+                        } else {
+                            store_face_tagged_if_ne<FULL>(offf, cur[r][j], pv, tag1, live);
+                        }
 #else
                         // (every lane stores at every compare without touching the exec mask: at its own offset when the compare
                         //  fired, into a trash slot when it did not -- the pre-round-5 stores, kept for comparison)
@@ -1244,14 +1307,10 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                 }
                 // (the runs behind the faces; records of a row in column order)
 #if TA_MASKED_STORES & 4
-                store_run_if_ne<FULL, 0, (int)(RSTRIDE / 4u)>(offr, cur[r][0], pcv[0], code0, live);
-                if constexpr (VPL > 1) store_run_if_ne<FULL, 1 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][1 % VPL], pcv[1 % VPL], code0, live);
-                if constexpr (VPL > 2) store_run_if_ne<FULL, 2 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][2 % VPL], pcv[2 % VPL], code0, live);
-                if constexpr (VPL > 3) store_run_if_ne<FULL, 3 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][3 % VPL], pcv[3 % VPL], code0, live);
-                if constexpr (VPL > 4) store_run_if_ne<FULL, 4 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][4 % VPL], pcv[4 % VPL], code0, live);
-                if constexpr (VPL > 5) store_run_if_ne<FULL, 5 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][5 % VPL], pcv[5 % VPL], code0, live);
-                if constexpr (VPL > 6) store_run_if_ne<FULL, 6 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][6 % VPL], pcv[6 % VPL], code0, live);
-                if constexpr (VPL > 7) store_run_if_ne<FULL, 7 % VPL, (int)(RSTRIDE / 4u)>(offr, cur[r][7 % VPL], pcv[7 % VPL], code0, live);
+                static_assert(VPL == 4 || VPL == 8, "the run stores are written out for four or eight voxels a lane");
+                store_runs4_if_ne<FULL, 0, (int)(RSTRIDE / 4u)>(offr, pcv[0], cur[r][0], cur[r][1 % VPL], cur[r][2 % VPL], cur[r][3 % VPL], code0, live);
+                if constexpr (VPL == 8)
+                    store_runs4_if_ne<FULL, 4, (int)(RSTRIDE / 4u)>(offr, cur[r][3 % VPL], cur[r][4 % VPL], cur[r][5 % VPL], cur[r][6 % VPL], cur[r][7 % VPL], code0, live);
                 static_assert(VPL <= 8, "the run stores are written out for eight voxels a lane");
 #else
 #pragma unroll

@@ -106,7 +106,10 @@ struct SumPack {
     }
 };
 // the tallest tile each kind of sweep kernel packs its sums for (launches clamp the tile height to it; results never depend on it)
-constexpr int tile_planes_cap(bool adjacency, int itemsize, int vpl) { (void)itemsize; return adjacency ? (vpl == 4 ? 48 : 32) : 16; }
+#ifndef TA_PLANES_CAP_ADJ8
+#define TA_PLANES_CAP_ADJ8 32
+#endif
+constexpr int tile_planes_cap(bool adjacency, int itemsize, int vpl) { (void)itemsize; return adjacency ? (vpl == 4 ? 48 : TA_PLANES_CAP_ADJ8) : 16; }
 
 // shift tile-local sums to global coordinates (origin A0,B0,C0): exact u64
 __device__ __forceinline__ void local_to_global(const LocalSums& L, uint64_t A0, uint64_t B0, uint64_t C0,
@@ -186,8 +189,11 @@ template <int NW, bool ADJ, bool MOM2, bool HOT, typename LDS, int NT = WAVES * 
 __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const int tid, const uint64_t A0,
                                              const uint64_t B0, const uint64_t C0, const uint32_t hot,
                                              const uint32_t wg) {
-    static_assert(LSLOTS * 2 <= (int)sizeof(S.wave[0].cql) + (int)sizeof(S.wave[0].cqc) && PSLOTS * 2 <= (int)sizeof(S.wave[1].cql) + (int)sizeof(S.wave[1].cqc),
-                  "the slot lists of the flush live in the run-record buffers of waves 0 and 1");
+    // (the record buffers are dead by now and lie back to back: the label list starts in wave 0's run arrays and must end
+    //  before wave 1's, the pair list starts in wave 1's and may run on into the buffers of the waves behind it)
+    static_assert(LSLOTS * 2 <= (int)sizeof(S.wave[0].cql) + (int)sizeof(S.wave[0].cqc) &&
+                  PSLOTS * 2 <= (int)sizeof(S.wave[1].cql) + (int)sizeof(S.wave[1].cqc) + (WAVES - 2) * (int)sizeof(S.wave[0]),
+                  "the slot lists of the flush live in the record buffers of the waves");
     uint16_t* const llist = reinterpret_cast<uint16_t*>(&S.wave[0].cql[0]);
     uint16_t* const plist = reinterpret_cast<uint16_t*>(&S.wave[1].cql[0]);
     const int lane = tid & 63;
