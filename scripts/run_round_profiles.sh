@@ -24,28 +24,47 @@ python3 bench.py 2>gpurun_out/${TAG}_bench_default.err | tail -1 >> gpurun_out/$
 for extra in "--config C3" "--config C2" "--config C2 --features 0x1f" "--config C1 --features 0x1f" "--features 0x0f" "--features 0x07" "--dims 1000 1000 1000"; do
   python3 bench.py $extra --no-cpu-baseline --no-secondary 2>/dev/null | tail -1 >> gpurun_out/${TAG}_bench.jsonl
 done
-# ablation builds (scripts/build_variant.py NAME -D...; results wrong by construction, only the time matters):
-#   abl1 = records produced, not consumed; abl3 = not even placed; nf01 = no axis-0 / axis-1 face records;
-#   noflush = the tile tables are not flushed; hot1 / hot2 / hot4 (all without flush) = the top-of-plane drains add nothing to
-#   the tables / ... and run no probe rounds / ... and read no records; nohotflush = no top-of-plane drains at all, no flush
+# ablation builds (scripts/build_variant.py NAME -D...; results wrong by construction, only the time matters), a CUMULATIVE ladder
+# on the WIDE shape (--shape 1: the kernel the headline names):
+#   noflush = the tile tables are not flushed; hot1 = ... and the top-of-plane drains add nothing to the tables; hot2 = ... and run
+#   no probe rounds; hot4 = ... and read neither keys nor records; noslow = ... and the in-plane drains / the end of the tile consume
+#   nothing; abl1 = nothing is consumed anywhere (records produced and stored); abl3 = not even placed (compares + counts + scan);
+#   nf01 (not cumulative) = no axis-0 / axis-1 face records; nomask = the pre-round-5 record stores (trash slot, five VALU a position)
 OUT=gpurun_out/${TAG}_ablations.txt
 : > $OUT
-for a in abl1 abl3 nf01 noflush hot1 hot2 hot4 nohotflush; do
-  if [ -f scratch/lib$a.so ]; then
+for a in base noflush hot1 hot2 hot4 noslow abl1 abl3 nf01 nomask base; do
+  if [ "$a" = base ] || [ -f scratch/lib$a.so ]; then
     echo "ablation $a" >> $OUT
-    TISSUE_SCAN_LIB=$R/scratch/lib$a.so python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f --iters 7 --no-check 2>&1 | grep "impl=0" | cut -c1-110 >> $OUT
-    TISSUE_SCAN_LIB=$R/scratch/lib$a.so python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f --iters 5 --no-check --no-ellipsoid 2>&1 | grep "impl=0" | sed 's/^/tissue-filled /' | cut -c1-124 >> $OUT
+    if [ "$a" = base ]; then unset TISSUE_SCAN_LIB; else export TISSUE_SCAN_LIB=$R/scratch/lib$a.so; fi
+    python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f --iters 7 --no-check --shape 1 2>&1 | grep "impl=0" | cut -c1-110 >> $OUT
+    python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f --iters 5 --no-check --no-ellipsoid --shape 1 2>&1 | grep "impl=0" | sed 's/^/tissue-filled /' | cut -c1-124 >> $OUT
   fi
 done
+unset TISSUE_SCAN_LIB
 if [ -f scratch/libreccount.so ]; then
-  echo "records per launch (flags 8..12: faces, runs, drains through drain_buffers; faces, runs through the top-of-plane drains)" >> $OUT
-  TISSUE_SCAN_LIB=$R/scratch/libreccount.so python3 scripts/probe_stamps.py C4 2>&1 | grep "counters" >> $OUT
-  TISSUE_SCAN_LIB=$R/scratch/libreccount.so python3 scripts/probe_stamps.py C4 --no-ellipsoid 2>&1 | grep "counters" | sed 's/^/tissue-filled /' >> $OUT
+  echo "records per launch, wide shape (flags 8..12: faces, runs, drains through the in-plane drain_buffers; faces, runs through the top-of-plane drains)" >> $OUT
+  TISSUE_SCAN_LIB=$R/scratch/libreccount.so python3 scripts/probe_stamps.py C4 --shape=1 2>&1 | grep "counters" >> $OUT
+  TISSUE_SCAN_LIB=$R/scratch/libreccount.so python3 scripts/probe_stamps.py C4 --shape=1 --no-ellipsoid 2>&1 | grep "counters" | sed 's/^/tissue-filled /' >> $OUT
+fi
+if [ -f scratch/libbarstamp.so ]; then
+  echo "a workgroup's life, wide shape (flags 8..11: cycles >> 8 summed over the waves: sweep of the tile, wait at the barrier before the flush, flush; wave-tiles)" >> $OUT
+  TISSUE_SCAN_LIB=$R/scratch/libbarstamp.so python3 scripts/probe_stamps.py C4 --shape=1 2>&1 | grep "counters" >> $OUT
+  TISSUE_SCAN_LIB=$R/scratch/libbarstamp.so python3 scripts/probe_stamps.py C4 --shape=1 --no-ellipsoid 2>&1 | grep "counters" | sed 's/^/tissue-filled /' >> $OUT
 fi
 echo "full" >> $OUT
 python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f 0x17 0x0f 0x07 --iters 7 --no-check 2>&1 | grep "impl=0" | cut -c1-110 >> $OUT
 python3 scripts/probe_impls.py C5 --impl 0 --feat 0x1f --iters 4 --no-check 2>&1 | grep "impl=0" | cut -c1-110 >> $OUT
 python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f 0x0f --iters 5 --no-check --no-ellipsoid 2>&1 | grep "impl=0" | sed 's/^/tissue-filled /' | cut -c1-124 >> $OUT
+python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f --iters 5 --no-check --no-ellipsoid --shape 0 2>&1 | grep "impl=0" | sed 's/^/tissue-filled narrow /' | cut -c1-124 >> $OUT
+python3 scripts/probe_impls.py C4 --impl 0 --feat 0x1f --iters 5 --no-check --shape 0 2>&1 | grep "impl=0" | sed 's/^/C4 narrow /' | cut -c1-124 >> $OUT
+python3 scripts/probe_impls.py C2 --dims 1024 1024 1024 --impl 0 --feat 0x1f 0x0f --iters 5 --no-check 2>&1 | grep "impl=0" | sed 's/^/1024^3 uint16 /' | cut -c1-124 >> $OUT
 python3 scripts/probe_impls.py C2 --impl 0 --feat 0x07 0x1f --iters 15 --no-check 2>&1 | grep "impl=0" | cut -c1-110 >> $OUT
 python3 scripts/probe_impls.py C4 --dims 1000 1000 1000 --impl 0 --feat 0x1f 0x0f --iters 7 --no-check 2>&1 | grep "impl=0" | sed 's/^/1000^3 /' | cut -c1-118 >> $OUT
 python3 scripts/probe_walls.py C2 2>&1 | tail -2 >> $OUT
+
+# PMC passes of the wide kernel and its abl1 / nf01 builds on C4 and on the tissue-filled C4 (instruction counts, LDS, waits)
+bash scripts/run_pmc_ablations.sh ${TAG} --shape 1 -- base abl1 nf01 > /dev/null 2>&1
+bash scripts/run_pmc_ablations.sh ${TAG}f --shape 1 --no-ellipsoid -- base abl1 > /dev/null 2>&1
+if [ -f scratch/pipes_bench ]; then ./scratch/pipes_bench > gpurun_out/${TAG}_pipes.txt 2>&1; fi
+python3 scripts/update_pmc_traffic.py C4 gpurun_out/prof_${TAG}_pmc.txt --note "default bench" > gpurun_out/${TAG}_traffic.txt 2>&1
+cp profiles/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json

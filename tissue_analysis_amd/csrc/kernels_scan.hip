@@ -48,7 +48,7 @@ namespace ta {
 #define TA_LSUM_REP 1    // 2: two replicas of a label slot's sums in the kernels with eight voxels a lane, by row parity -- measured: slower
 #endif
 #ifndef TA_FCAP
-#define TA_FCAP 192
+#define TA_FCAP 256
 #endif
 #ifndef TA_RCAP
 #define TA_RCAP 128
@@ -522,12 +522,13 @@ __device__ __forceinline__ uint32_t label_probe_issue(LDS& S, const bool pend, u
 #ifndef TA_ABL_HOT
 #define TA_ABL_HOT 0
 #endif
-// the first NF groups of 64 records of a face buffer that holds at least that many and at most 64 more (NF = 2: 128 .. 192,
-// NF = 1: 64 .. 127 -- what is left moves to the front, one record per lane)
+// the LAST NF groups of 64 records of a face buffer that holds at least that many: face records carry no order, so the drain
+// takes the top of the buffer and nothing has to move (round 4 took the front and moved what was left down: one LDS read and
+// one write a drain, and a buffer that could not hold more than 64 records behind the groups)
 template <int NF, typename LDS, typename WLDS>
 __device__ __forceinline__ void drain_face_groups(const SweepArgs* kp, LDS& S, WLDS& W, int lane, uint32_t& fcount) {
     static_assert(NF == 1 || NF == 2, "one or two lookups per lane in lockstep");
-    static_assert(FCAP >= 64 * NF && FCAP <= 64 * 3, "what is left after the groups moves to the front one record per lane");
+    static_assert(FCAP >= 64 * NF, "the buffer holds the groups");
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     if (TA_ABLATE >= 1) { fcount = 0u; return; }
 #ifdef TA_ABL_NOHOT
@@ -537,11 +538,10 @@ __device__ __forceinline__ void drain_face_groups(const SweepArgs* kp, LDS& S, W
     uint2 rec[NF];
 #pragma unroll
     for (int g = 0; g < NF; ++g) {
-        if (TA_ABL_HOT < 4) rec[g] = W.frec[lane + 64 * g];
+        if (TA_ABL_HOT < 4) rec[g] = W.frec[fcount - 64u * (uint32_t)NF + (uint32_t)(lane + 64 * g)];
         else { rec[g].x = (uint32_t)lane * 2654435761u; rec[g].y = rec[g].x >> 7; asm volatile("" : "+v"(rec[g].x), "+v"(rec[g].y)); }
     }
-    const uint32_t rem = fcount - 64u * NF;                               // <= 64
-    const uint2 tail = W.frec[(uint32_t)lane < rem ? 64u * NF + (uint32_t)lane : 0u];
+    const uint32_t rem = fcount - 64u * NF;                               // what stays, where it is
     uint32_t lo[NF], hi[NF], slot[NF];
     uint64_t k[NF], key[NF];
     bool live[NF], pend[NF];
@@ -563,7 +563,6 @@ __device__ __forceinline__ void drain_face_groups(const SweepArgs* kp, LDS& S, W
         if (TA_ABL_HOT < 3) { k[g] = S.pkeys[slot[g]]; k1[g] = S.pkeys[(slot[g] + 1u) & (PSLOTS - 1)]; }
         else { k[g] = key[g]; k1[g] = key[g]; asm volatile("" :: "v"(slot[g])); }
     }
-    if ((uint32_t)lane < rem) W.frec[lane] = tail;                         // (behind the reads of the same slots: LDS keeps a wave's order)
 #pragma unroll
     for (int g = 0; g < NF; ++g) {
         const bool home = k[g] == key[g] || k[g] == EMPTY_KEY;            // (it is there, or it goes there)

@@ -13,6 +13,9 @@ namespace ta {
 #ifndef TA_WAVES
 #define TA_WAVES 4
 #endif
+#ifndef TA_FLUSH_BOX_READ
+#define TA_FLUSH_BOX_READ 1      // the flush reads a label's global box and sends only the bounds its tile extends
+#endif
 #ifndef TA_PSLOTS
 #define TA_PSLOTS 512
 #endif
@@ -284,9 +287,24 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
 #pragma unroll
         for (int k = 0; k < (MOM2 ? NSUM : 4); ++k) atomicAdd(row + k, (unsigned long long)g[k]);
         int32_t* box = priv ? reinterpret_cast<int32_t*>(hr + NSUM) : &A.boxes[(uint64_t)label * NBOX];
-        atomicMin(box + 0, (int32_t)(A0 + bx0)); atomicMin(box + 3, -(int32_t)(A0 + bx3));
-        atomicMin(box + 1, (int32_t)(B0 + bx1)); atomicMin(box + 4, -(int32_t)(B0 + bx4));
-        atomicMin(box + 2, (int32_t)(C0 + bx2)); atomicMin(box + 5, -(int32_t)(C0 + bx5));
+        // The global box is READ first (plain loads) and only the bounds this tile extends are sent: a cell meets ~10 tiles and its
+        // box stops moving after the outermost ones.  A stale value out of a cache is an OLDER one -- boxes only ever shrink towards
+        // their minima -- so a skip decided on it is always safe; the price is one more round trip in a flush that waits for several.
+        const int32_t m0 = (int32_t)(A0 + bx0), m1 = (int32_t)(B0 + bx1), m2 = (int32_t)(C0 + bx2);
+        const int32_t m3 = -(int32_t)(A0 + bx3), m4 = -(int32_t)(B0 + bx4), m5 = -(int32_t)(C0 + bx5);
+#if TA_FLUSH_BOX_READ
+        const int2 g01 = *reinterpret_cast<const int2*>(box), g23 = *reinterpret_cast<const int2*>(box + 2), g45 = *reinterpret_cast<const int2*>(box + 4);
+        if (m0 < g01.x) atomicMin(box + 0, m0);
+        if (m1 < g01.y) atomicMin(box + 1, m1);
+        if (m2 < g23.x) atomicMin(box + 2, m2);
+        if (m3 < g23.y) atomicMin(box + 3, m3);
+        if (m4 < g45.x) atomicMin(box + 4, m4);
+        if (m5 < g45.y) atomicMin(box + 5, m5);
+#else
+        atomicMin(box + 0, m0); atomicMin(box + 3, m3);
+        atomicMin(box + 1, m1); atomicMin(box + 4, m4);
+        atomicMin(box + 2, m2); atomicMin(box + 5, m5);
+#endif
     }
 }
 
