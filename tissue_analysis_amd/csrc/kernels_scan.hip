@@ -1146,7 +1146,45 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         if (has_prev) load_rows(p_lo - 1, cur);
         load_rows(p_lo, nxt); load_halo(p_lo, nxt_up, nxt_leftv);
     } else {
-        if (has_prev) {
+#ifndef TA_PROLOGUE_OVERLAP
+#define TA_PROLOGUE_OVERLAP 1
+#endif
+        if constexpr (!PAD && TA_PROLOGUE_OVERLAP && RB == 2 && VPL == 8) {       // (the tiles of eight voxels a lane: C5 6.79 -> 6.63 ms, C4 unchanged; the narrow tiles measured +1 %: not there)
+            // The plane BEFORE the tile and the tile's first plane in flight TOGETHER (round 4 landed one, then issued the other:
+            // a workgroup began its life with two memory latencies back to back, ~13 k cycles of a background tile's 210 k).
+            // The older plane goes into ordinary registers -- by hand-issued loads as well: a load the compiler knows about in
+            // front of this loop makes it wait for `vmcnt(0)` inside every iteration, behind the next plane's hand-issued loads
+            // (measured: +6 ... +9 %) -- and ONE counted wait lets the landing zone's loads, which are younger, stay in flight.
+            if (has_prev) {
+                const char* row0 = next_row0;
+#ifndef TA_ABL_L2
+                next_row0 += plane_bytes;
+#endif
+                constexpr int NQ = WIDE8 ? 2 : 1;                    // 16-byte quads a row
+                u32x4 t[RB * NQ];
+#pragma unroll
+                for (int r = 0; r < RB; ++r)
+#pragma unroll
+                    for (int q = 0; q < NQ; ++q)
+                        asm volatile("global_load_dwordx4 %0, %1, %2" : "=&v"(t[r * NQ + q]) : "v"(lane_off), "s"(row0 + (int64_t)r * rowbytes + 16 * q) : "memory");
+                issue_plane();
+                // the landing zone's loads: eight voxels a lane 6 strips + the left voxel, else two rows + the row above + the left voxel
+                if constexpr (WIDE8) asm volatile("s_waitcnt vmcnt(7)" : "+v"(t[0]), "+v"(t[1]), "+v"(t[NQ]), "+v"(t[2 * NQ - 1]) :: "memory");
+                else                 asm volatile("s_waitcnt vmcnt(4)" : "+v"(t[0]), "+v"(t[RB - 1]) :: "memory");
+#pragma unroll
+                for (int r = 0; r < RB; ++r) {
+                    if constexpr (WIDE8) {
+                        const u32x4 a = t[r * NQ], c4 = t[r * NQ + NQ - 1];
+                        cur[r][0] = a.x; cur[r][1] = a.y; cur[r][2] = a.z; cur[r][3] = a.w;
+                        cur[r][4 % VPL] = c4.x; cur[r][5 % VPL] = c4.y; cur[r][6 % VPL] = c4.z; cur[r][7 % VPL] = c4.w;
+                    } else {
+                        unpack_strip<T, VPL>(t[r * NQ], cur[r]);
+                    }
+                }
+            } else {
+                issue_plane();
+            }
+        } else if (has_prev) {
             issue_plane();
             land(ZoneA{}, std::false_type{});
 #pragma unroll
@@ -1157,8 +1195,10 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
                 for (int j = 0; j < VPL; ++j) dump_up[j] = 0u;
                 pad_plane(cur, dump_up, dump_l);
             }
+            issue_plane();
+        } else {
+            issue_plane();
         }
-        issue_plane();
     }
 
 #ifdef TA_STAMPS
