@@ -16,7 +16,7 @@ OBJDIR = os.path.join(CSRC, "_obj")
 LIB = os.path.join(HERE, "libtissue_scan.so")
 SOURCES = ["ta_api.hip", "kernels_basic.hip", "kernels_scan.hip", "kernels_walls.hip", "kernels_wallsort.hip", "kernels_wallmedian.hip", "kernels_census.hip",
            "kernels_pairsort.hip"]
-HEADERS = ["ta_device.h", "ta_kernels.h", "ta_sweep_common.h", "ta_pin_tables.inc", os.path.join("..", "..", "include", "tissue_scan.h")]
+HEADERS = ["ta_device.h", "ta_kernels.h", "ta_sweep_common.h", "ta_sweep_switches.h", "ta_pin_tables.inc", os.path.join("..", "..", "include", "tissue_scan.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden",
          "-Wall", "-Wno-unused-function", "-DTA_BUILD"]
 # Per-source extra flags.  (The sweep kernels live on a hand-set VGPR budget -- the plane in flight is pinned above it -- and

@@ -34,25 +34,7 @@
 
 namespace ta {
 
-#ifndef TA_XCD_CHUNK
-#define TA_XCD_CHUNK 4   // consecutive tiles given to one XCD (0 = plain order); 4 = one row of tiles of a 1024-wide volume
-#endif
 // the hot (most common) label of the volume gets a private row per workgroup, also with adjacency
-#ifndef TA_HOT_ADJ
-#define TA_HOT_ADJ 1
-#endif
-#ifndef TA_FACE_COMBINE
-#define TA_FACE_COMBINE 0   // 1: the top-of-plane face drains add equal consecutive records as one (segment heads only) -- measured: no gain
-#endif
-#ifndef TA_LSUM_REP
-#define TA_LSUM_REP 1    // 2: two replicas of a label slot's sums in the kernels with eight voxels a lane, by row parity -- measured: slower
-#endif
-#ifndef TA_FCAP
-#define TA_FCAP 256
-#endif
-#ifndef TA_RCAP
-#define TA_RCAP 128
-#endif
 constexpr int FCAP = TA_FCAP, RCAP = TA_RCAP;           // record capacities of a wave's buffers
 constexpr int FTRASH = FCAP, RTRASH = RCAP + 1;          // the trash slots of the branch-free stores, behind the buffers
 constexpr uint32_t ROWID_MASK = 0x7FFFFC00u;            // bits of a run code that name the row (b, a, and the zero bits above)
@@ -119,23 +101,9 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x) {
 // the step of the offset run in the lanes that fired, one scalar move puts EXEC back: two vector instructions a position.
 // (Inline asm: the compiler never sees EXEC change.  No manual wait states are needed between a VALU write of EXEC and
 // LDS / VALU instructions that run under it; DPP instructions are the exception -- emit_done() pads for them.)
-#ifndef TA_MASKED_STORES
-#define TA_MASKED_STORES 7      // bits: 1 = the plane's axis-0 faces, 2 = a row's axis-1 faces, 4 = its runs
-#endif
 // FULL: every lane of the wave is live at the call (EXEC is put back to all ones), else `live` is the mask to put back
-#ifndef TA_CMPX_STYLE
-#define TA_CMPX_STYLE 0
-#endif
-#if TA_CMPX_STYLE == 0
 #define TA_CMPX(a, b) "v_cmpx_ne_u32_e32 vcc, " a ", " b "\n\t"
 #define TA_CMPX_PART(a, b) TA_CMPX(a, b)
-#elif TA_CMPX_STYLE == 1
-#define TA_CMPX(a, b) "v_cmpx_ne_u32_e32 vcc, " a ", " b "\n\ts_nop 4\n\t"
-#define TA_CMPX_PART(a, b) TA_CMPX(a, b)
-#else
-#define TA_CMPX(a, b) "v_cmp_ne_u32_e32 vcc, " a ", " b "\n\ts_mov_b64 exec, vcc\n\t"
-#define TA_CMPX_PART(a, b) "v_cmp_ne_u32_e32 vcc, " a ", " b "\n\ts_and_b64 exec, exec, vcc\n\t"
-#endif
 template <bool FULL>
 __device__ __forceinline__ void store_face_if_ne(uint32_t& off, const uint32_t v, const uint32_t pv, const uint64_t live) {
     if constexpr (FULL)
@@ -481,9 +449,6 @@ __device__ __forceinline__ void drain_buffers(const SweepArgs* kp, LDS& S, WLDS&
 // (the slot is ours now), the key (it is there) or another key (on to the next slot).  No read-then-CAS pair, no branch on
 // what was read: slot and state move by selects, the only divergent instruction is the masked compare-and-swap itself.
 // (Per-lane branches are what made the probe loops of drain_buffers slow: ~100 scalar / branch instructions a round.)
-#ifndef TA_PROBE_NORTN
-#define TA_PROBE_NORTN 1
-#endif
 template <typename LDS>
 __device__ __forceinline__ uint64_t pair_probe_issue(LDS& S, const bool pend, uint32_t& slot, const uint64_t k, const uint64_t key) {
 #if TA_PROBE_NORTN
@@ -519,9 +484,6 @@ __device__ __forceinline__ uint32_t label_probe_issue(LDS& S, const bool pend, u
 
 // TA_ABL_HOT (ablations of the hot drains, cumulative, results wrong by construction): 1 = nothing is added to the tables
 // (no count / sum / box atomics), 2 = ... and no probe rounds, 3 = ... and no home-slot reads, 4 = ... and no record reads
-#ifndef TA_ABL_HOT
-#define TA_ABL_HOT 0
-#endif
 // the LAST NF groups of 64 records of a face buffer that holds at least that many: face records carry no order, so the drain
 // takes the top of the buffer and nothing has to move (round 4 took the front and moved what was left down: one LDS read and
 // one write a drain, and a buffer that could not hold more than 64 records behind the groups)
@@ -591,19 +553,6 @@ __device__ __forceinline__ void drain_face_groups(const SweepArgs* kp, LDS& S, W
         const bool ok = live[g] && !pend[g];
 #ifdef TA_ABL_SHARE1
         if (TA_ABL_HOT < 1) { if (ok) pcnt_add(S, (slot[g] + (uint32_t)lane * 7u) & (PSLOTS - 1), rec[g].y >> 30); }
-#elif TA_FACE_COMBINE && !TA_PCNT64
-        // Records that follow each other in the buffer and are EQUAL -- a wall seen at consecutive columns, by consecutive
-        // positions of one lane -- are one segment: its first lane adds the segment's length, the others add nothing.  (An LDS
-        // atomic costs the CU ~7.7 cycles times the lanes of the instruction that share an address: a flat wall put 16+ of the
-        // 64 lanes on one counter.)  Equal records have equal keys, slots and states, so a segment is all `ok` or not at all.
-        if (TA_ABL_HOT < 1) {
-            const uint32_t px = lane_shr1(rec[g].x, ~rec[g].x), py = lane_shr1(rec[g].y, rec[g].y);      // (lane 0: never equal)
-            const bool same = ok && px == rec[g].x && py == rec[g].y;
-            const uint64_t cont = __builtin_amdgcn_ballot_w64(same);                 // lane j continues the segment of lane j - 1
-            const uint64_t after = ~((cont >> (uint32_t)lane) >> 1);                 // from lane + 1 on: the first 0 of `cont` ends it
-            const uint32_t len = 1u + (uint32_t)__builtin_ctzll(after);              // (the shifted-in zeros end every segment)
-            if (ok && !same) atomicAdd(&S.pcnt[slot[g] * 3u + (rec[g].y >> 30)], len);
-        }
 #else
         if (TA_ABL_HOT < 1) { if (ok) pcnt_add(S, slot[g], rec[g].y >> 30); }
 #endif
@@ -790,9 +739,6 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 #define TA_PIN_ADJ2 82
 #define TA_CAP_ADJ2 78
 // TA_PLANES_IN_FLIGHT = 2 (experiment): a second landing zone behind the first, 82 + 27 = 109 registers, FOUR waves per SIMD
-#ifndef TA_PLANES_IN_FLIGHT
-#define TA_PLANES_IN_FLIGHT 1
-#endif
 #define TA_PIN_ADJ2B 96
 #define TA_CAP_MOM 72
 // the PADDED kernels (partial tiles of a volume whose rows are 16-byte aligned: interior-style loads, edge-style
@@ -842,12 +788,6 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     auto& W = S.wave[w];
     // the hot drain sites take every record of a buffer at once (drain_faces_all / drain_runs_all); the rare ones -- a row too
     // big for the buffers placed in pieces, the end of the tile -- keep the compact group-by-group drain_buffers
-#ifndef TA_DRAIN_ALL
-#define TA_DRAIN_ALL 1
-#endif
-#ifndef TA_DRAIN_ALL_U16
-#define TA_DRAIN_ALL_U16 1    // the full tiles of uint16 volumes too (their kernel sits at 125 VGPRs: see the build's register check)
-#endif
 // TA_FDRAIN1: tiles of eight voxels a lane put twice the records of a plane step into the same buffers; with 64 .. 127 faces
 // left after a step, the next one's often do not fit and the whole buffer goes through the in-plane drain (29 % of C4's face
 // records, 43 % of the tissue-filled volume's, against 13 / 14 % with four voxels a lane).  With one group of 64 leaving at
@@ -855,12 +795,6 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
 // filled 1.38 - 1.44 vs 1.39 - 1.46, C5 6.79 / 6.83 vs 6.78 / 6.86): where a record is drained does not matter.  On since
 // round 5 (with the predicated stores: C4 0.972 -> 0.965, filled 1.392 -> 1.367 / 1.390 ms in one call -- within the noise, and
 // the in-plane drain with its per-lane probe loops becomes the rare path it is meant to be).
-#ifndef TA_FDRAIN1
-#define TA_FDRAIN1 1
-#endif
-#ifndef TA_FDRAIN
-#define TA_FDRAIN 128         // face records in the buffer from which the top-of-plane drain takes the full groups
-#endif
     constexpr bool DRAIN_ALL = ADJ && TA_DRAIN_ALL && FCAP % 64 == 0 && RCAP % 64 == 0 && (TA_DRAIN_ALL_U16 || VPL == 4) && RB == 2 && !EDGE;
 
     const T* vol = reinterpret_cast<const T*>(A.vol);
@@ -1146,9 +1080,6 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
         if (has_prev) load_rows(p_lo - 1, cur);
         load_rows(p_lo, nxt); load_halo(p_lo, nxt_up, nxt_leftv);
     } else {
-#ifndef TA_PROLOGUE_OVERLAP
-#define TA_PROLOGUE_OVERLAP 1
-#endif
         if constexpr (!PAD && TA_PROLOGUE_OVERLAP && RB == 2 && VPL == 8) {       // (the tiles of eight voxels a lane: C5 6.79 -> 6.63 ms, C4 unchanged; the narrow tiles measured +1 %: not there)
             // The plane BEFORE the tile and the tile's first plane in flight TOGETHER (round 4 landed one, then issued the other:
             // a workgroup began its life with two memory latencies back to back, ~13 k cycles of a background tile's 210 k).
@@ -1491,9 +1422,6 @@ static ScanSplit scan_split(const SweepArgs& a, int itemsize) {
     return s;
 }
 
-#ifndef TA_PERSIST_SINGLE_QUEUE
-#define TA_PERSIST_SINGLE_QUEUE 0
-#endif
 // The next tile of a persistent workgroup: from the list of its own XCD (workgroups are dealt round-robin over the 8 XCDs;
 // an XCD's list is every eighth CHUNK of TA_XCD_CHUNK consecutive tiles -- neighbours along axes 2 and 1, so that the halo
 // row a tile reads is the row its neighbour on the same XCD / L2 reads at about the same time -- plus its share of the last,
@@ -1647,12 +1575,6 @@ __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_
 // TA_PERSIST (measured, NOT adopted: profiles/r04_NOTES.md): 1280 persistent workgroups that take tiles from per-XCD queues and
 // leave the flush's global atomics in flight.  C4 1.30 ms against 1.07 ms with a workgroup per tile -- the same instructions
 // (SQ_INSTS_* equal to 1 %), but the waves are parked twice as long (SQ_WAIT_ANY 2.3e9 against 1.1e9 quad-cycles).
-#ifndef TA_PERSIST
-#define TA_PERSIST 0
-#endif
-#ifndef TA_PERSIST_WGS
-#define TA_PERSIST_WGS (256 * 5)       // what the chip holds at five workgroups per CU (fewer tiles: one workgroup each)
-#endif
 template <typename T, int VPL, int RB, bool MOM2>
 __global__ void __launch_bounds__(WAVES * 64) __attribute__((amdgpu_num_vgpr(TA_CAP_ADJ2))) scan_two_rows_kernel(SweepArgs A, ScanSplit sp, uint32_t wg0) {
     static_assert(RB == 2 && VPL == 4, "the 13-register landing zone holds two rows of four voxels a lane");
@@ -1729,13 +1651,7 @@ static void launch_scan_tt(hipStream_t s, const SweepArgs& a, hipEvent_t ev_star
 constexpr int RB32_ADJ = 2, RB32_MOM = 4;
 // uint16 volumes with adjacency: 4 voxels a lane like the uint32 kernel (8-byte strips read as the first half of a 16-byte
 // load: the same 13-register landing zone, the same plane state, five waves per SIMD) or 8 (the pre-round-3 shape, 125 VGPRs)
-#ifndef TA_U16_VPL
-#define TA_U16_VPL 8
-#endif
 constexpr int VPL16_ADJ = TA_U16_VPL;
-#ifndef TA_U16_MOM_RB
-#define TA_U16_MOM_RB 2      // rows a wave of the moments-only uint16 kernel (512 columns each)
-#endif
 constexpr int RB16_MOM = TA_U16_MOM_RB;
 
 uint64_t sweep_grid_size(const SweepArgs& a, int itemsize, bool adjacency) {

@@ -4,24 +4,10 @@
 // pair -> per-axis face counts) with global atomics.
 #pragma once
 #include "ta_kernels.h"
+#include "ta_sweep_switches.h"
 
 namespace ta {
 
-#ifndef TA_ABLATE
-#define TA_ABLATE 0     // experiments only: 1 = records are produced but not consumed
-#endif
-#ifndef TA_WAVES
-#define TA_WAVES 4
-#endif
-#ifndef TA_FLUSH_BOX_READ
-#define TA_FLUSH_BOX_READ 1      // the flush reads a label's global box and sends only the bounds its tile extends
-#endif
-#ifndef TA_PSLOTS
-#define TA_PSLOTS 512
-#endif
-#ifndef TA_LSLOTS
-#define TA_LSLOTS 128
-#endif
 constexpr int WAVES = TA_WAVES;   // PRODUCER waves per workgroup, stacked along axis 1 (a kernel with a consumer wave has one more)
 constexpr int LSLOTS = TA_LSLOTS; // label table slots per workgroup
 constexpr int PSLOTS = TA_PSLOTS; // pair table slots per workgroup
@@ -35,9 +21,6 @@ constexpr uint32_t LABEL_LIMIT = 1u << 28;    // max_label < 2^28: the two top b
 // TA_PCNT64 (measured, not adopted): a pair's three per-axis face counts of ONE tile in a u64 LDS word, 21 bits each (a tile
 // holds at most 16 rows x 512 columns x 64 planes = 2^19 voxels, so a field cannot carry into the next): 8 bytes per slot
 // instead of 12, but every LDS atomic on it costs twice the cycles of a u32 one
-#ifndef TA_PCNT64
-#define TA_PCNT64 0
-#endif
 constexpr int PCNT_BITS = 21;
 constexpr uint64_t PCNT_MASK = (1ull << PCNT_BITS) - 1ull;
 
@@ -109,9 +92,6 @@ struct SumPack {
     }
 };
 // the tallest tile each kind of sweep kernel packs its sums for (launches clamp the tile height to it; results never depend on it)
-#ifndef TA_PLANES_CAP_ADJ8
-#define TA_PLANES_CAP_ADJ8 32
-#endif
 constexpr int tile_planes_cap(bool adjacency, int itemsize, int vpl) { (void)itemsize; return adjacency ? (vpl == 4 ? 48 : TA_PLANES_CAP_ADJ8) : 16; }
 
 // shift tile-local sums to global coordinates (origin A0,B0,C0): exact u64
