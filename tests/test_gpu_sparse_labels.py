@@ -287,3 +287,25 @@ def test_plane_events_length_with_a_size_one_axis():
     ev = ctx.plane_events()
     assert ev.size == ctx.owned_planes() and int(ev.sum()) == int((a[:, 1:, 0] != a[:, :-1, 0]).sum())
     ctx.close()
+
+
+def test_the_census_in_one_pass_and_where_it_gives_up(gpu_ctx):
+    """The census of a volume whose maximum is not known reads the voxels ONCE (the workgroups' label sets go through a list that
+    sizes the table); a volume of noise overflows the list and takes the two passes -- the same answer either way."""
+    rng = np.random.default_rng(11)
+    # tissue-like, whole 16-byte rows, the id no set slot can hold (0xFFFFFFFF) among them
+    vol = scatter_ids(voronoi((40, 64, 512), 400, 8, np.uint32), 8, (1 << 32) - 1)
+    vol[3, 5, 100:140] = 0xFFFFFFFF
+    gpu_ctx.set_volume(vol)
+    top, present = gpu_ctx.label_census()
+    assert top == 0xFFFFFFFF and np.array_equal(present, np.unique(vol))
+    # noise: two million voxels, nearly as many ids -- more than the list holds
+    noise = rng.integers(0, 1 << 32, size=(128, 128, 128), dtype=np.uint64).astype(np.uint32)
+    gpu_ctx.set_volume(noise)
+    top, present = gpu_ctx.label_census()
+    assert top == int(noise.max()) and np.array_equal(present, np.unique(noise))
+    # uint16 noise (every id of the type, many evictions from the sets, but few enough for the list)
+    n16 = rng.integers(0, 1 << 16, size=(16, 64, 512), dtype=np.uint32).astype(np.uint16)
+    gpu_ctx.set_volume(n16)
+    top, present = gpu_ctx.label_census()
+    assert top == int(n16.max()) and np.array_equal(present, np.unique(n16))

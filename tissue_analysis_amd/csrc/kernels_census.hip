@@ -61,10 +61,21 @@ __global__ void __launch_bounds__(256) census_mark_kernel(const T* __restrict__ 
 // the workgroup, after its last row: 0.77 ms.
 constexpr int CENSUS_ROWS_PER_BLOCK = 64;
 constexpr int CENSUS_SEEN_LOG2 = 11, CENSUS_SEEN = 1 << CENSUS_SEEN_LOG2;
+constexpr int CENSUS_LIST_PARTS = 256;           // a label list is kept in parts, each with its own cursor (one word that 16 k workgroups
+                                                 // add to is a queue: returning atomics on one address take ~0.4 us each)
+constexpr int CENSUS_LIST_HEAD = 2 * CENSUS_LIST_PARTS;      // words before the entries: { asked for, maximum } per part
 
-template <typename T>
+//
+// LIST (one pass over a volume whose maximum is not known yet, so the table cannot be sized): the labels leave the workgroup for a
+// LIST in memory instead of the table, kept in CENSUS_LIST_PARTS parts of `cap` entries (a workgroup writes to part blockIdx mod
+// parts): `list[2 p]` = entries asked for in part p (more than `cap`: the list was too short and the caller takes the two passes),
+// `list[2 p + 1]` = the largest label listed there (the largest of all = the volume's maximum: every id is listed at least
+// once), part p's entries from `list + CENSUS_LIST_HEAD + p * cap` on; a workgroup asks for the places of its whole set with
+// ONE atomic, a label pushed out of its slot on the way with one of its own (tissue: a few hundred a volume; a volume of noise
+// fills the list and is told to go away).
+template <typename T, bool LIST>
 __global__ void __launch_bounds__(256) census_mark_rows_kernel(const T* __restrict__ vol, uint32_t rowvec, uint64_t nrows, uint32_t strips,
-                                                               uint32_t fold, uint2* census, uint8_t* touched) {
+                                                               uint32_t fold, uint2* census, uint8_t* touched, uint32_t* list, uint32_t cap) {
     constexpr int PER = 16 / (int)sizeof(T);
     const uint4* v4 = reinterpret_cast<const uint4*>(vol);
     const uint32_t strip = blockIdx.x % strips;
@@ -81,12 +92,20 @@ __global__ void __launch_bounds__(256) census_mark_rows_kernel(const T* __restri
     __syncthreads();
     uint64_t row = chunk * CENSUS_ROWS_PER_BLOCK * fold + sub;
     const bool active = col < rowvec && sub < fold && row < nrows;
+    auto out = [&](uint32_t v) {
+        if (!LIST) { census_mark(census, touched, v); return; }
+        uint32_t* const head = list + 2u * (blockIdx.x % CENSUS_LIST_PARTS);
+        if (__hip_atomic_load(head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) > cap) return;     // (too short already: nobody will read it)
+        const uint32_t at = atomicAdd(head, 1u);
+        if (at < cap) list[CENSUS_LIST_HEAD + (uint64_t)(blockIdx.x % CENSUS_LIST_PARTS) * cap + at] = v;
+        atomicMax(head + 1, v);
+    };
     auto mark = [&](uint32_t v) {
-        if (v == NONE) { census_mark(census, touched, v); return; }        // (the one id that cannot sit in the set)
+        if (v == NONE) { out(v); return; }                                  // (the one id that cannot sit in the set)
         const uint32_t slot = (v * 2654435761u) >> (32 - CENSUS_SEEN_LOG2);
         if (seen[slot] == v) return;
         const uint32_t old = atomicExch(&seen[slot], v);
-        if (old != v && old != NONE) census_mark(census, touched, old);
+        if (old != v && old != NONE) out(old);
     };
     if (active) {
     uint32_t above[PER];
@@ -146,14 +165,43 @@ __global__ void __launch_bounds__(256) census_mark_rows_kernel(const T* __restri
     }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < CENSUS_SEEN; i += 256)
-        if (seen[i] != NONE) census_mark(census, touched, seen[i]);
+    if (!LIST) {
+        for (int i = threadIdx.x; i < CENSUS_SEEN; i += 256)
+            if (seen[i] != NONE) census_mark(census, touched, seen[i]);
+    } else {
+        __shared__ uint32_t placed[3];                      // entries of the workgroup, where they start in the list, their maximum
+        if (threadIdx.x < 3) placed[threadIdx.x] = 0u;
+        __syncthreads();
+        uint32_t mine = 0u, top = 0u;
+        for (int i = threadIdx.x; i < CENSUS_SEEN; i += 256)
+            if (seen[i] != NONE) { ++mine; top = max(top, seen[i]); }
+        const uint32_t off = mine ? atomicAdd(&placed[0], mine) : 0u;
+        if (mine) atomicMax(&placed[2], top);
+        __syncthreads();
+        uint32_t* const head = list + 2u * (blockIdx.x % CENSUS_LIST_PARTS);
+        if (threadIdx.x == 0 && placed[0]) { placed[1] = atomicAdd(head, placed[0]); atomicMax(head + 1, placed[2]); }
+        __syncthreads();
+        uint32_t* const part = list + CENSUS_LIST_HEAD + (uint64_t)(blockIdx.x % CENSUS_LIST_PARTS) * cap;
+        uint32_t at = placed[1] + off;
+        for (int i = threadIdx.x; i < CENSUS_SEEN; i += 256)
+            if (seen[i] != NONE) { if (at < cap) part[at] = seen[i]; ++at; }
+    }
 }
 
 // a census from a LIST of ids (the union over the ranks of a partitioned volume: every rank then ranks alike)
 __global__ void __launch_bounds__(256) census_from_ids_kernel(const uint32_t* __restrict__ ids, uint64_t n, uint2* census, uint8_t* touched) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) { atomicOr(&census[ids[i] >> 5].x, 1u << (ids[i] & 31u)); touched[ids[i] >> 17] = 1; }
+}
+
+// ... and from the parts of a label list (census_mark_rows_kernel, LIST): blockIdx.y = the part
+__global__ void __launch_bounds__(256) census_from_list_kernel(const uint32_t* __restrict__ list, uint32_t cap, uint2* census, uint8_t* touched) {
+    const uint32_t n = list[2u * blockIdx.y];
+    const uint32_t* ids = list + CENSUS_LIST_HEAD + (uint64_t)blockIdx.y * cap;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const uint32_t v = ids[i];
+        atomicOr(&census[v >> 5].x, 1u << (v & 31u)); touched[v >> 17] = 1;
+    }
 }
 
 __device__ __forceinline__ uint32_t block_sum_256(uint32_t v, uint32_t* lds) {
@@ -284,28 +332,37 @@ static uint64_t census_blocks(uint32_t max_label) { return (census_words(max_lab
 uint64_t census_scratch_bytes(uint32_t max_label) { return (census_blocks(max_label) + 1) * sizeof(uint32_t) + census_blocks(max_label) + 16; }
 static uint8_t* census_touched(void* scratch, uint32_t max_label) { return (uint8_t*)((uint32_t*)scratch + census_blocks(max_label) + 1); }
 
+namespace {
+struct CensusRows { uint32_t rowvec, strips, fold; uint64_t nrows, chunks, done; };
+// rows of whole 16-byte vectors: the strips walk down the real rows.  Otherwise the volume as one long run of 256-vector
+// pseudo-rows: what is above a vector is then no neighbour of it, but the workgroup's LDS set -- the part that keeps the table
+// out of the streaming loop -- works the same.  `done`: the voxels the row kernel takes (0: it does not apply)
+CensusRows census_rows(const void* vol, int itemsize, uint64_t n, int64_t row_len) {
+    CensusRows r{};
+    if (((uintptr_t)vol & 15) != 0 || n == 0) return r;
+    const int per = 16 / itemsize;
+    const bool real_rows = row_len > 0 && (row_len * itemsize) % 16 == 0 && n % (uint64_t)row_len == 0;
+    r.rowvec = real_rows ? (uint32_t)(row_len * itemsize / 16) : 256u;
+    r.nrows = real_rows ? n / (uint64_t)row_len : (n / per) / 256u;
+    r.strips = r.rowvec >= 256 ? (r.rowvec + 255) / 256 : 1;
+    r.fold = r.rowvec >= 256 ? 1 : 256 / r.rowvec;
+    r.chunks = (r.nrows + (uint64_t)CENSUS_ROWS_PER_BLOCK * r.fold - 1) / ((uint64_t)CENSUS_ROWS_PER_BLOCK * r.fold);
+    if (r.nrows && r.chunks * r.strips < (1ull << 31)) r.done = r.nrows * r.rowvec * (uint64_t)per;
+    return r;
+}
+}  // namespace
+
 void launch_census_mark(hipStream_t s, const void* vol, int itemsize, uint64_t n, int64_t row_len, void* census, void* scratch,
                         uint32_t max_label) {
     uint8_t* touched = census_touched(scratch, max_label);
     if (n == 0) return;
     const int per = 16 / itemsize;
-    uint64_t done = 0;                                  // voxels the row kernel takes
-    if (((uintptr_t)vol & 15) == 0) {
-        // rows of whole 16-byte vectors: the strips walk down the real rows.  Otherwise the volume as one long run of
-        // 256-vector pseudo-rows: what is above a vector is then no neighbour of it, but the workgroup's LDS set -- the part
-        // that keeps the table out of the streaming loop -- works the same
-        const bool real_rows = row_len > 0 && (row_len * itemsize) % 16 == 0 && n % (uint64_t)row_len == 0;
-        const uint32_t rowvec = real_rows ? (uint32_t)(row_len * itemsize / 16) : 256u;
-        const uint64_t nrows = real_rows ? n / (uint64_t)row_len : (n / per) / 256u;
-        const uint32_t strips = rowvec >= 256 ? (rowvec + 255) / 256 : 1;
-        const uint32_t fold = rowvec >= 256 ? 1 : 256 / rowvec;
-        const uint64_t chunks = (nrows + (uint64_t)CENSUS_ROWS_PER_BLOCK * fold - 1) / ((uint64_t)CENSUS_ROWS_PER_BLOCK * fold);
-        if (nrows && chunks * strips < (1ull << 31)) {
-            const dim3 grid((unsigned)(chunks * strips));
-            if (itemsize == 2) hipLaunchKernelGGL(census_mark_rows_kernel<uint16_t>, grid, dim3(256), 0, s, (const uint16_t*)vol, rowvec, nrows, strips, fold, (uint2*)census, touched);
-            else               hipLaunchKernelGGL(census_mark_rows_kernel<uint32_t>, grid, dim3(256), 0, s, (const uint32_t*)vol, rowvec, nrows, strips, fold, (uint2*)census, touched);
-            done = nrows * rowvec * (uint64_t)per;
-        }
+    const CensusRows r = census_rows(vol, itemsize, n, row_len);
+    const uint64_t done = r.done;
+    if (done) {
+        const dim3 grid((unsigned)(r.chunks * r.strips));
+        if (itemsize == 2) hipLaunchKernelGGL((census_mark_rows_kernel<uint16_t, false>), grid, dim3(256), 0, s, (const uint16_t*)vol, r.rowvec, r.nrows, r.strips, r.fold, (uint2*)census, touched, (uint32_t*)nullptr, 0u);
+        else               hipLaunchKernelGGL((census_mark_rows_kernel<uint32_t, false>), grid, dim3(256), 0, s, (const uint32_t*)vol, r.rowvec, r.nrows, r.strips, r.fold, (uint2*)census, touched, (uint32_t*)nullptr, 0u);
     }
     if (done == n) return;
     // what is left (less than a pseudo-row), or a volume that does not start on a 16-byte boundary: the flat kernel
@@ -315,6 +372,32 @@ void launch_census_mark(hipStream_t s, const void* vol, int itemsize, uint64_t n
     const unsigned blocks = stream_blocks(nvec ? nvec : m);
     if (itemsize == 2) hipLaunchKernelGGL(census_mark_kernel<uint16_t>, dim3(blocks), dim3(256), 0, s, (const uint16_t*)rest, m, nvec, (uint2*)census, touched);
     else               hipLaunchKernelGGL(census_mark_kernel<uint32_t>, dim3(blocks), dim3(256), 0, s, (const uint32_t*)rest, m, nvec, (uint2*)census, touched);
+}
+
+// ONE pass over a volume of unknown maximum (see census_mark_rows_kernel, LIST): its labels, with repeats, into `list` (a zeroed
+// head of census_list_head_bytes(), then census_list_parts() parts of `cap` entries).  Returns false -- nothing enqueued -- where
+// the row kernel does not take the whole volume.  Afterwards the head holds { entries asked for, maximum } per part (asked for
+// > cap anywhere: too short); launch_census_from_list marks them.
+uint64_t census_list_head_bytes() { return CENSUS_LIST_HEAD * sizeof(uint32_t); }
+uint32_t census_list_parts() { return CENSUS_LIST_PARTS; }
+uint64_t census_list_capacity(uint64_t n) {             // per part.  Tissue lists ~40 labels per 64 rows of a strip; a volume of noise every voxel
+    const uint64_t cap = n / 256 / CENSUS_LIST_PARTS;
+    return cap < 4096 ? 4096 : (cap > (1u << 22) ? (1u << 22) : cap);
+}
+void launch_census_from_list(hipStream_t s, const void* list, uint32_t cap, uint32_t most, void* census, void* scratch, uint32_t max_label) {
+    if (most == 0) return;
+    unsigned bx = (most + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipLaunchKernelGGL(census_from_list_kernel, dim3(bx, CENSUS_LIST_PARTS), dim3(256), 0, s, (const uint32_t*)list, cap, (uint2*)census,
+                       census_touched(scratch, max_label));
+}
+bool launch_census_list(hipStream_t s, const void* vol, int itemsize, uint64_t n, int64_t row_len, void* list, uint32_t cap) {
+    const CensusRows r = census_rows(vol, itemsize, n, row_len);
+    if (r.done != n || n == 0) return false;
+    const dim3 grid((unsigned)(r.chunks * r.strips));
+    if (itemsize == 2) hipLaunchKernelGGL((census_mark_rows_kernel<uint16_t, true>), grid, dim3(256), 0, s, (const uint16_t*)vol, r.rowvec, r.nrows, r.strips, r.fold, (uint2*)nullptr, (uint8_t*)nullptr, (uint32_t*)list, cap);
+    else               hipLaunchKernelGGL((census_mark_rows_kernel<uint32_t, true>), grid, dim3(256), 0, s, (const uint32_t*)vol, r.rowvec, r.nrows, r.strips, r.fold, (uint2*)nullptr, (uint8_t*)nullptr, (uint32_t*)list, cap);
+    return true;
 }
 
 void launch_census_from_ids(hipStream_t s, const uint32_t* ids_dev, uint64_t n, void* census, void* scratch, uint32_t max_label) {

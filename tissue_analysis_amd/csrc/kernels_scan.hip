@@ -801,7 +801,11 @@ __device__ __forceinline__ void wave_scan(const SweepArgs& A, const SweepArgs* k
     const int64_t n1 = A.n1, n2 = A.n2, plane = n1 * n2;
     const int64_t b_wave0 = (int64_t)b_tile0 + (int64_t)w * RB;
     const int64_t c0g = (int64_t)c_tile0 + (int64_t)lane * VPL;
+#ifdef TA_ABL_NOHALO                                        // 1: a workgroup's first wave reads no row above (the row another tile owns); 2: no wave does
+    const bool has_up = ADJ && b_wave0 > 0 && (TA_ABL_NOHALO == 1 ? w != 0 : false);
+#else
     const bool has_up = ADJ && b_wave0 > 0;
+#endif
     const bool has_left = ADJ && c_tile0 > 0;
     const bool has_prev = ADJ && p_lo > 0;
     const uint32_t lane_c = (uint32_t)lane * VPL;

@@ -91,7 +91,7 @@ struct ta_ctx {
     int first_owned = 0;
 
     // sparse label ids: the census of the volume's ids and the copy of the volume in their ranks (what the sweep then reads)
-    DevBuf census, census_ids, compact_vol;
+    DevBuf census, census_ids, compact_vol, census_list;      // (census_list: the label list of the one-pass census, ~n / 256 entries)
     uint32_t census_max = 0;            // ids 0 .. census_max have a bit
     int64_t census_n = -1;              // ids present, -1 = no census
     int64_t vol_max = -1;               // largest label of the resident buffer (halo included), -1 = not known
@@ -508,7 +508,7 @@ TA_API int ta_ctx_destroy(ta_ctx* c) {
     c->wall_counts.release();
     c->wall_stage.release();
     c->wall_medians.release();
-    c->census.release(); c->census_ids.release(); c->compact_vol.release();
+    c->census.release(); c->census_ids.release(); c->compact_vol.release(); c->census_list.release();
     if (c->h_small) (void)hipHostFree(c->h_small);
     for (auto& e : c->ev) if (e) (void)hipEventDestroy(e);
     for (auto& e : c->ring) if (e) (void)hipEventDestroy(e);
@@ -1086,7 +1086,10 @@ namespace {
 int build_census(ta_ctx* c, const uint32_t* ids, uint32_t n_ids) {
     int rc;
     const uint64_t nvox = (uint64_t)c->mdims[0] * c->mdims[1] * c->mdims[2];
-    uint32_t top = 0;
+    uint32_t top = 0, listed = 0;
+    uint64_t cap = 0;
+    bool have_list = false;
+    DevBuf& list = c->census_list;                      // (kept: allocating and freeing it costs more than the pass it saves)
     if (ids) {
         for (uint32_t i = 1; i < n_ids; ++i)
             if (ids[i] <= ids[i - 1]) return fail(TA_EINVAL, "ids must be ascending and unique (ids[%u]=%u after %u)", i, ids[i], ids[i - 1]);
@@ -1095,10 +1098,32 @@ int build_census(ta_ctx* c, const uint32_t* ids, uint32_t n_ids) {
         top = (uint32_t)c->vol_max;                     // (ta_volume_max_label has been here, and only this library writes
                                                         //  a volume it uploaded itself: no second pass)
     } else {
-        ta::launch_max_label(c->stream, c->vol, c->itemsize, nvox, maxlab_dev(c));
-        TA_HIP(hipMemcpyAsync(&top, maxlab_dev(c), sizeof(top), hipMemcpyDeviceToHost, c->stream));
-        TA_HIP(hipStreamSynchronize(c->stream));
-        c->vol_max = top;
+        // ONE pass over the voxels where the maximum is not known: the workgroups' label sets go to a list, the list gives the
+        // maximum (the table's size) and is marked afterwards -- a few hundred thousand entries against a second read of the volume
+        cap = ta::census_list_capacity(nvox);
+        const uint32_t parts = ta::census_list_parts();
+        if (list.reserve(ta::census_list_head_bytes() + (uint64_t)parts * cap * 4) == TA_OK) {
+            TA_HIP(hipMemsetAsync(list.p, 0, ta::census_list_head_bytes(), c->stream));
+            if (ta::launch_census_list(c->stream, c->vol, c->itemsize, nvox, c->mdims[2], list.p, (uint32_t)cap)) {
+                std::vector<uint32_t> head;
+                try { head.resize(2 * (size_t)parts); } catch (...) { return fail(TA_ENOMEM, "out of host memory"); }
+                TA_HIP(hipMemcpyAsync(head.data(), list.p, ta::census_list_head_bytes(), hipMemcpyDeviceToHost, c->stream));
+                TA_HIP(hipStreamSynchronize(c->stream));
+                have_list = true;
+                for (uint32_t p = 0; p < parts; ++p) {
+                    if (head[2 * p] > cap) have_list = false;
+                    if (head[2 * p] > listed) listed = head[2 * p];
+                    if (head[2 * p + 1] > top) top = head[2 * p + 1];
+                }
+                if (have_list) c->vol_max = top; else top = 0;
+            }
+        }
+        if (!have_list) {                               // (rows that are not whole vectors, or a volume of noise: the two passes)
+            ta::launch_max_label(c->stream, c->vol, c->itemsize, nvox, maxlab_dev(c));
+            TA_HIP(hipMemcpyAsync(&top, maxlab_dev(c), sizeof(top), hipMemcpyDeviceToHost, c->stream));
+            TA_HIP(hipStreamSynchronize(c->stream));
+            c->vol_max = top;
+        }
     }
     c->census_n = -1;
     if ((rc = c->census.reserve(ta::census_bytes(top))) != TA_OK) return rc;
@@ -1110,6 +1135,8 @@ int build_census(ta_ctx* c, const uint32_t* ids, uint32_t n_ids) {
         if ((rc = staged.reserve((uint64_t)n_ids * 4)) != TA_OK) { scratch.release(); return rc; }
         e = hipMemcpyAsync(staged.p, ids, (uint64_t)n_ids * 4, hipMemcpyHostToDevice, c->stream);
         if (e == hipSuccess) ta::launch_census_from_ids(c->stream, (const uint32_t*)staged.p, n_ids, c->census.p, scratch.p, top);
+    } else if (e == hipSuccess && !ids && have_list) {
+        ta::launch_census_from_list(c->stream, list.p, (uint32_t)cap, listed, c->census.p, scratch.p, top);
     } else if (e == hipSuccess && !ids) {
         ta::launch_census_mark(c->stream, c->vol, c->itemsize, nvox, c->mdims[2], c->census.p, scratch.p, top);
     }

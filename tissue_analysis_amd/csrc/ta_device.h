@@ -64,6 +64,14 @@ __device__ __forceinline__ uint32_t hash_pair(uint32_t lo, uint32_t hi) {
     return hash_u32(lo * 0x9E3779B1u ^ hash_u32(hi));
 }
 
+// the adds / minima of a tile flush into the device-global tables.  TA_FLUSH_SCOPE (ta_sweep_switches.h) is the memory scope they are
+// issued with: agent = performed where every XCD sees them; workgroup (an ABLATION: results wrong across XCDs) = in the issuing XCD's L2
+#ifndef TA_FLUSH_SCOPE
+#define TA_FLUSH_SCOPE __HIP_MEMORY_SCOPE_AGENT
+#endif
+__device__ __forceinline__ void flush_add(unsigned long long* p, unsigned long long v) { (void)__hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, TA_FLUSH_SCOPE); }
+__device__ __forceinline__ void flush_min(int32_t* p, int32_t v) { (void)__hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, TA_FLUSH_SCOPE); }
+
 // Insert/accumulate one pair into the device-global table.  Slots only ever go EMPTY -> key
 // inside a launch, so a stale EMPTY read is repaired by the CAS and a non-EMPTY read is final.
 // (`h`, `k`: the pair's home slot and the key a caller has read from it already -- it issues that read early, with other
@@ -79,9 +87,9 @@ __device__ __forceinline__ void pair_add_global_from(const PairTable& pt, uint32
         }
         if (k == key) {
             unsigned long long* f = (unsigned long long*)&pt.faces[3ull * h];
-            if (f0) atomicAdd(f + 0, (unsigned long long)f0);
-            if (f1) atomicAdd(f + 1, (unsigned long long)f1);
-            if (f2) atomicAdd(f + 2, (unsigned long long)f2);
+            if (f0) flush_add(f + 0, (unsigned long long)f0);
+            if (f1) flush_add(f + 1, (unsigned long long)f1);
+            if (f2) flush_add(f + 2, (unsigned long long)f2);
             return;
         }
         h = (h + 1) & pt.mask;

@@ -90,6 +90,11 @@ uint64_t census_bytes(uint32_t max_label);              // { bits, ids below } p
 uint64_t census_scratch_bytes(uint32_t max_label);
 void launch_census_mark(hipStream_t s, const void* vol, int itemsize, uint64_t n, int64_t row_len, void* census, void* scratch,
                         uint32_t max_label);
+uint64_t census_list_head_bytes();
+uint32_t census_list_parts();
+void launch_census_from_list(hipStream_t s, const void* list, uint32_t cap, uint32_t most, void* census, void* scratch, uint32_t max_label);
+uint64_t census_list_capacity(uint64_t n);
+bool launch_census_list(hipStream_t s, const void* vol, int itemsize, uint64_t n, int64_t row_len, void* list, uint32_t cap);
 void launch_census_from_ids(hipStream_t s, const uint32_t* ids_dev, uint64_t n, void* census, void* scratch, uint32_t max_label);
 void launch_census_scan(hipStream_t s, void* census, uint32_t max_label, void* scratch, uint32_t* ids_out, uint32_t** total_dev);
 void launch_census_rank(hipStream_t s, const void* vol, void* out, int itemsize, uint64_t n, const void* census, uint32_t max_label,

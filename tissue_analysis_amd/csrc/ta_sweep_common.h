@@ -205,6 +205,86 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
     __syncthreads();
     const int nl = (int)S.fcnt[0], np = ADJ ? (int)S.fcnt[1] : 0;
 
+    // TRANSPOSED label flush (TA_FLUSH_TRANSPOSE): a label's NSUM sums are consecutive u64 words of one global row, and a global atomic
+    // is a request to the memory side per cache line a wave instruction touches.  Lane = label sends every add of an instruction to a
+    // different row (64 requests, ten instructions a label); lane = (label, word) sends 64 consecutive words of ~6 rows.  The sums go
+    // through LDS for that: the pair table's keys and counts are read into registers first (two pairs a thread at most; their home
+    // slots' global reads are in flight from then on), the sums are staged where the pair table was, and the pairs' adds go last.
+    constexpr int NS = MOM2 ? NSUM : 4;
+    constexpr bool TR = ADJ && !RESET && TA_FLUSH_TRANSPOSE != 0 && !TA_PCNT64 && PSLOTS <= 2 * NT &&
+                        (size_t)LSLOTS * NSUM * 8 <= sizeof(S.pkeys) + sizeof(S.pcnt);
+    if constexpr (TR) {
+        static_assert(!TR || offsetof(LDS, pcnt) == offsetof(LDS, pkeys) + sizeof(S.pkeys), "the staged sums run from the pair keys on into the pair counts");
+        uint64_t pkey[2], gkey[2]; uint32_t pf[2][3], ghome[2]; bool plive[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = NT - 1 - tid + q * NT;
+            plive[q] = j < np;
+            pkey[q] = gkey[q] = 0ull; ghome[q] = 0u; pf[q][0] = pf[q][1] = pf[q][2] = 0u;
+#ifndef TA_ABL_NOFLUSH_PAIRS
+            if (plive[q]) {
+                const int i = plist[j];
+                pkey[q] = S.pkeys[i];
+                ghome[q] = hash_pair((uint32_t)(pkey[q] >> 32), (uint32_t)pkey[q]) & A.pairs.mask;
+                gkey[q] = __hip_atomic_load(&A.pairs.keys[ghome[q]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                pf[q][0] = S.pcnt[i * 3 + 0]; pf[q][1] = S.pcnt[i * 3 + 1]; pf[q][2] = S.pcnt[i * 3 + 2];
+            }
+#endif
+        }
+        __syncthreads();                                   // (every pair is in registers: the table's space is free)
+        uint64_t* const stage = reinterpret_cast<uint64_t*>(&S.pkeys[0]);
+        uint64_t* const hot_rows = HOT ? hot_rows_of(A) : nullptr;
+        uint64_t* const hr = hot_rows + (uint64_t)wg * HOTW;
+#ifndef TA_ABL_NOFLUSH_LABELS
+        for (int j = tid; j < nl; j += NT) {
+            const int i = llist[j];
+            const uint32_t label = S.lkeys[i];
+            LocalSums L;
+            L.n = L.sa = L.sb = L.sc = L.saa = L.sab = L.sac = L.sbb = L.sbc = L.scc = 0;
+#pragma unroll
+            for (int rp = 0; rp < LDS::REP; ++rp) {
+                uint64_t w[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+                for (int k = 0; k < NW; ++k) w[k] = S.lsum[(i * LDS::REP + rp) * NW + k];
+                LDS::Pack::template unpack_add<MOM2>(w, L);
+            }
+            uint64_t g[NSUM];
+            local_to_global(L, A0, B0, C0, g);
+            const bool ok = label <= A.max_label;
+            if (!ok) atomicOr(&A.flags[FLAG_RANGE], 1u);
+#pragma unroll
+            for (int k = 0; k < NS; ++k) stage[j * NS + k] = ok ? g[k] : 0ull;
+            if (ok) {
+                const bool priv = HOT && hot_rows && label == hot;
+                int32_t* box = priv ? reinterpret_cast<int32_t*>(hr + NSUM) : &A.boxes[(uint64_t)label * NBOX];
+                const int32_t m0 = (int32_t)(A0 + S.lbox[i * 8 + 0]), m1 = (int32_t)(B0 + S.lbox[i * 8 + 1]), m2 = (int32_t)(C0 + S.lbox[i * 8 + 2]);
+                const int32_t m3 = -(int32_t)(A0 + S.lbox[i * 8 + 3]), m4 = -(int32_t)(B0 + S.lbox[i * 8 + 4]), m5 = -(int32_t)(C0 + S.lbox[i * 8 + 5]);
+                const int2 g01 = *reinterpret_cast<const int2*>(box), g23 = *reinterpret_cast<const int2*>(box + 2), g45 = *reinterpret_cast<const int2*>(box + 4);
+                if (m0 < g01.x) flush_min(box + 0, m0);
+                if (m1 < g01.y) flush_min(box + 1, m1);
+                if (m2 < g23.x) flush_min(box + 2, m2);
+                if (m3 < g23.y) flush_min(box + 3, m3);
+                if (m4 < g45.x) flush_min(box + 4, m4);
+                if (m5 < g45.y) flush_min(box + 5, m5);
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < nl * NS; idx += NT) {
+            const int j = idx / NS, k = idx - j * NS;
+            const uint32_t label = S.lkeys[llist[j]];
+            const uint64_t v = stage[idx];
+            if (v) {
+                const bool priv = HOT && hot_rows && label == hot;
+                unsigned long long* row = (unsigned long long*)(priv ? hr : &A.sums[(uint64_t)label * NSUM]);
+                flush_add(row + k, (unsigned long long)v);
+            }
+        }
+#endif
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+            if (plive[q])
+                pair_add_global_from(A.pairs, (uint32_t)(pkey[q] >> 32), (uint32_t)pkey[q], pf[q][0], pf[q][1], pf[q][2], A.flags, ghome[q], gkey[q]);
+    } else {
     // -- the pairs, from the last thread down: the home slot of the pair in the device-global table is READ first and looked
     //    at afterwards (the first global round trip of the probe is in flight while the rest is prepared)
 #ifdef TA_ABL_NOFLUSH_PAIRS
@@ -265,7 +345,7 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
         uint64_t* hr = hot_rows + (uint64_t)wg * HOTW;
         unsigned long long* row = (unsigned long long*)(priv ? hr : &A.sums[(uint64_t)label * NSUM]);
 #pragma unroll
-        for (int k = 0; k < (MOM2 ? NSUM : 4); ++k) atomicAdd(row + k, (unsigned long long)g[k]);
+        for (int k = 0; k < (MOM2 ? NSUM : 4); ++k) flush_add(row + k, (unsigned long long)g[k]);
         int32_t* box = priv ? reinterpret_cast<int32_t*>(hr + NSUM) : &A.boxes[(uint64_t)label * NBOX];
         // The global box is READ first (plain loads) and only the bounds this tile extends are sent: a cell meets ~10 tiles and its
         // box stops moving after the outermost ones.  A stale value out of a cache is an OLDER one -- boxes only ever shrink towards
@@ -274,17 +354,18 @@ __device__ __forceinline__ void flush_tables(const SweepArgs& A, LDS& S, const i
         const int32_t m3 = -(int32_t)(A0 + bx3), m4 = -(int32_t)(B0 + bx4), m5 = -(int32_t)(C0 + bx5);
 #if TA_FLUSH_BOX_READ
         const int2 g01 = *reinterpret_cast<const int2*>(box), g23 = *reinterpret_cast<const int2*>(box + 2), g45 = *reinterpret_cast<const int2*>(box + 4);
-        if (m0 < g01.x) atomicMin(box + 0, m0);
-        if (m1 < g01.y) atomicMin(box + 1, m1);
-        if (m2 < g23.x) atomicMin(box + 2, m2);
-        if (m3 < g23.y) atomicMin(box + 3, m3);
-        if (m4 < g45.x) atomicMin(box + 4, m4);
-        if (m5 < g45.y) atomicMin(box + 5, m5);
+        if (m0 < g01.x) flush_min(box + 0, m0);
+        if (m1 < g01.y) flush_min(box + 1, m1);
+        if (m2 < g23.x) flush_min(box + 2, m2);
+        if (m3 < g23.y) flush_min(box + 3, m3);
+        if (m4 < g45.x) flush_min(box + 4, m4);
+        if (m5 < g45.y) flush_min(box + 5, m5);
 #else
-        atomicMin(box + 0, m0); atomicMin(box + 3, m3);
-        atomicMin(box + 1, m1); atomicMin(box + 4, m4);
-        atomicMin(box + 2, m2); atomicMin(box + 5, m5);
+        flush_min(box + 0, m0); flush_min(box + 3, m3);
+        flush_min(box + 1, m1); flush_min(box + 4, m4);
+        flush_min(box + 2, m2); flush_min(box + 5, m5);
 #endif
+    }
     }
 }
 

@@ -50,6 +50,9 @@
 #ifndef TA_FLUSH_BOX_READ
 #define TA_FLUSH_BOX_READ 1      // the flush reads a label's global box and sends only the bounds its tile extends
 #endif
+#ifndef TA_FLUSH_TRANSPOSE
+#define TA_FLUSH_TRANSPOSE 1     // the flush sends a label's sums lane = (label, word): consecutive lanes, consecutive words of a global row
+#endif
 #ifndef TA_PLANES_CAP_ADJ8
 #define TA_PLANES_CAP_ADJ8 32    // the tallest tile the kernels of eight voxels a lane pack their sums for (SumPack)
 #endif
@@ -87,6 +90,8 @@
 //   TA_ABL_NOSLOW the in-plane drains and the end of the tile consume nothing;  TA_ABL_NOHOT no top-of-plane drains
 //   TA_ABL_NOFACE0 / TA_ABL_NOFACE1 no axis-0 / axis-1 face records;  TA_ABL_NOSUMS, TA_ABL_NOBOX, TA_ABL_NOBOXHOT, TA_ABL_NOPCNT, TA_ABL_NOLOOP,
 //   TA_ABL_SHARE1 (every lane of an add its own address), TA_ABL_L2 (every plane re-reads the tile's first: an L2-resident run)
+//   TA_ABL_NOHALO = 1 a workgroup's first wave reads no row above (the row another tile owns: 12.5 % of the bytes fetched); 2 = no wave does
+//   TA_FLUSH_SCOPE the memory scope of the flush's global adds (gfx950 encodes agent and workgroup scope alike: nothing to measure)
 //   TA_RECCOUNT   flags[8..12] = face / run records and calls through the in-plane drain, faces / runs through the top-of-plane drains
 //   TA_BARSTAMP   flags[8..11] = cycles >> 8 over the waves: sweep of the tile, wait at the barrier before the flush, flush; wave-tiles
 //   TA_STAMPS     per-phase s_memtime stamps of the narrow kernels (scripts/probe_stamps.py);  TA_DBG_EMIT an in-kernel check of the
