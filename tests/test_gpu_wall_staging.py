@@ -101,3 +101,40 @@ def test_rows_that_are_not_aligned_for_vector_loads():
             view.copy_(torch.from_numpy(vol.view(np.int16 if dtype == np.uint16 else np.int32)).to("cuda:0"))
             ctx.set_volume_device(view.data_ptr(), np.dtype(dtype).itemsize, vol.shape, keep=view)
             check(vol, ctx)
+
+
+@pytest.mark.parametrize("keyed", ["1", "0"])
+def test_the_grouped_fetch_from_keys_and_from_records(stage_records, keyed):
+    """The grouped fetch sorts KEYS and linear voxel indices the fetch kernels write themselves (volumes below 2^32 voxels;
+    coordinates rebuilt from the index in the last pass); TA_WALL_KEYED=0 sorts the records of the plain fetch, as larger
+    volumes do.  Both against the brute force: two-label keys of 32 and 64 bits, the second walk."""
+    os.environ["TA_WALL_KEYED"] = keyed
+    try:
+        check(voronoi((20, 33, 300), 50, 81, np.uint16))
+        big = voronoi((12, 17, 140), 30, 82, np.uint32)
+        big[big > 0] += 70000                                            # 17-bit labels: 64-bit sort keys
+        check(big)
+        stage_records(0)                                                 # every cell through the second walk
+        check(voronoi((9, 20, 260), 30, 85, np.uint16))
+    finally:
+        os.environ.pop("TA_WALL_KEYED", None)
+
+
+def test_the_two_grouped_fetches_agree_on_axes_that_are_not_c_ordered():
+    """(a pair's voxels come in MEMORY order, which only for C-ordered images is the order of the brute force: here the fetch
+    from keys -- coordinates rebuilt from the linear index through the axis permutation -- against the fetch from records)"""
+    for vol in (np.asfortranarray(voronoi((14, 18, 40), 25, 83, np.uint16)), np.transpose(voronoi((10, 24, 36), 25, 84, np.uint32), (1, 0, 2))):
+        got = {}
+        for keyed in ("1", "0"):
+            os.environ["TA_WALL_KEYED"] = keyed
+            rv = ResidentVolume(vol)
+            try:
+                got[keyed] = rv.ctx.wall_voxels(by_pair=True)[:3]
+            finally:
+                rv.close()
+                os.environ.pop("TA_WALL_KEYED", None)
+        for a, b in zip(got["1"], got["0"]):
+            assert a.size and np.array_equal(a, b)
+        lo, hi, co = got["1"]
+        own = vol[co[:, 0], co[:, 1], co[:, 2]].astype(np.int64)
+        assert np.all((own == lo) | (own == hi))

@@ -140,7 +140,17 @@ struct WallArgs {
     uint2* out_pairs;              // [n] (lo, hi)
     int32_t* out_coords;           // [n][3], array-axis order
     int32_t inv[3];                // inv[i] = memory axis of array axis i
+    // the grouped fetch (kernels_wallsort.hip): key_bits != 0 -> COPY / EMIT write SORT KEYS (lo << key_bits | hi: 4 bytes where two
+    // labels fit 32 bits, else 8) to `out_pairs` and the voxel's memory-order linear index (u32) to `out_coords` instead of records
+    uint32_t key_bits;
 };
+// a record as the grouped fetch wants it (see WallArgs::key_bits)
+__device__ __forceinline__ void wall_put_key(const WallArgs& A, uint64_t at, uint32_t lo, uint32_t hi, int32_t ma, int32_t mb, int32_t mc) {
+    const uint64_t key = ((uint64_t)lo << A.key_bits) | hi;
+    if (2u * A.key_bits <= 32u) reinterpret_cast<uint32_t*>(A.out_pairs)[at] = (uint32_t)key;
+    else                        reinterpret_cast<uint64_t*>(A.out_pairs)[at] = key;
+    reinterpret_cast<uint32_t*>(A.out_coords)[at] = (uint32_t)(((uint64_t)ma * (uint64_t)A.n1 + (uint64_t)mb) * (uint64_t)A.n2 + (uint64_t)mc);
+}
 
 constexpr int WALL_CURSORS = 256;
 constexpr uint32_t WALL_COPY_CELLS = 16;
@@ -307,6 +317,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             out_pairs = A.out_pairs + base;
             out_coords = A.out_coords + 3 * base;
         }
+        const uint64_t emit_base = EMIT ? base : 0ull;
         uint32_t K[WNJ][WALL_KEPT];             // COUNT: the first four labels of each column, as t = (label XOR v) - 1
         uint32_t nn = 0;                        // records of column j in byte j
         bool many = false;                      // a voxel of this lane has more than four labels
@@ -358,8 +369,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))
             }
             auto put = [&](uint32_t td) {
                 const uint32_t m = v ^ (td + 1u);
-                out_pairs[pos] = make_uint2(v < m ? v : m, v < m ? m : v);
-                *reinterpret_cast<Int3*>(out_coords + 3u * pos) = xyz;
+                if (A.key_bits) {
+                    wall_put_key(A, emit_base + pos, v < m ? v : m, v < m ? m : v, (int32_t)ma, (int32_t)b, (int32_t)(colq + (uint32_t)j));
+                } else {
+                    out_pairs[pos] = make_uint2(v < m ? v : m, v < m ? m : v);
+                    *reinterpret_cast<Int3*>(out_coords + 3u * pos) = xyz;
+                }
                 ++pos;
             };
             // distinct t in increasing order, one per round.  The first one is tmin; where it equals the largest there is
@@ -504,6 +519,7 @@ __global__ void __launch_bounds__(256) wall_copy_kernel(WallArgs A, uint32_t nce
         xyz.y = A.inv[1] == 0 ? c.ma : (A.inv[1] == 1 ? c.mb : mc);
         xyz.z = A.inv[2] == 0 ? c.ma : (A.inv[2] == 1 ? c.mb : mc);
         const uint32_t other = rec.own ^ (rec.t + 1u);
+        if (A.key_bits) { wall_put_key(A, c.dst + r, rec.own < other ? rec.own : other, rec.own < other ? other : rec.own, c.ma, c.mb, mc); return; }
         A.out_pairs[c.dst + r] = make_uint2(rec.own < other ? rec.own : other, rec.own < other ? other : rec.own);
         *reinterpret_cast<Int3*>(A.out_coords + 3 * (c.dst + r)) = xyz;
     };
@@ -644,7 +660,7 @@ static WallArgs wall_args(const void* vol, int64_t n0, int64_t n1, int64_t n2, c
     a.counts = b.counts; a.cell_base = b.cell_base; a.lane_counts = b.lane_counts; a.offsets = b.offsets;
     a.stage = b.stage; a.cursors = b.cursors; a.region = b.stage ? b.region : 0u; a.status = b.status;
     a.todo = b.todo; a.ntodo = 0;
-    a.out_pairs = nullptr; a.out_coords = nullptr;
+    a.out_pairs = nullptr; a.out_coords = nullptr; a.key_bits = 0u;
     a.inv[0] = 0; a.inv[1] = 1; a.inv[2] = 2;
     return a;
 }
@@ -673,11 +689,11 @@ void launch_wall_count(hipStream_t s, const void* vol, int itemsize, int64_t n0,
 }
 
 void launch_wall_fetch(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2, const WallBuffers& b,
-                       bool wide, uint32_t not_staged, uint32_t* out_pairs, int32_t* out_coords, const int perm[3]) {
+                       bool wide, uint32_t not_staged, uint32_t* out_pairs, int32_t* out_coords, const int perm[3], int key_bits) {
     const WallPlan p = wall_plan(n0, n1, n2);
     if (p.cells == 0) return;
     WallArgs a = wall_args(vol, n0, n1, n2, p, b);
-    a.out_pairs = (uint2*)out_pairs; a.out_coords = out_coords;
+    a.out_pairs = (uint2*)out_pairs; a.out_coords = out_coords; a.key_bits = (uint32_t)key_bits;
     for (int k = 0; k < 3; ++k) a.inv[perm[k]] = k;          // perm[k] = array axis of memory axis k
     if (a.region) {
         const dim3 grid((unsigned)((p.cells + 4 * WALL_COPY_CELLS - 1) / (4 * WALL_COPY_CELLS)));

@@ -17,6 +17,9 @@ namespace ta {
 
 constexpr int RS_WAVES = 4, RS_PER_WAVE = 1024, RS_TILE = RS_WAVES * RS_PER_WAVE;      // keys per workgroup
 constexpr int RS_MAX_DIGIT_BITS = 10;
+#ifndef TA_RS_RUNS
+#define TA_RS_RUNS 1       // digits are counted a RUN of equal neighbours at a time (0: a key at a time, round 4)
+#endif
 
 // the passes a key of `key_bits` takes: as few as digits of at most 10 bits allow, all of the same width
 static int rs_passes(int key_bits) { return (key_bits + RS_MAX_DIGIT_BITS - 1) / RS_MAX_DIGIT_BITS; }
@@ -44,12 +47,25 @@ __device__ __forceinline__ uint64_t digit_peers(const uint32_t d, const bool val
     return peers;
 }
 
+// Counting digits: the records of a wall are neighbours in memory and stay neighbours through every (stable) pass, so a wave's 64
+// keys hold RUNS of equal digits -- and an LDS atomic costs the CU ~8 cycles times the lanes that share its address
+// (profiles/r05_pipes.txt).  Only the first lane of a run adds, the run's length: one DPP shift, one ballot, a count of trailing zeros.
+// `d` of a lane without a key must differ from every digit.  Returns the length for the first lane of a run, 0 for the others.
+__device__ __forceinline__ uint32_t run_length_at_head(const uint32_t d, const int lane) {
+    const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)~d, (int)d, 0x138, 0xf, 0xf, false);    // wave_shr:1 (lane 0: no lane before it)
+    const bool head = d != before;
+    const uint64_t heads = __builtin_amdgcn_ballot_w64(head);
+    const uint64_t later = (heads >> 1) >> lane;                                  // the heads behind this lane
+    const uint32_t len = later ? (uint32_t)__builtin_ctzll(later) + 1u : 64u - (uint32_t)lane;
+    return head ? len : 0u;
+}
+
 // (Counting the digits with one fire-and-forget LDS atomic per key puts many lanes on one address -- a wall's records are
 //  neighbours in memory -- which the CU serialises; counting by one lane per group of equal digits, through digit_peers, was
 //  built and is SLOWER -- C2 1.98 against 1.44 ms for the grouped fetch: three rounds of eight ballots a chunk and a
 //  read-modify-write the wave has to wait for cost more than the serialised atomics nobody waits for.)
 template <typename K, int DB>
-__global__ void __launch_bounds__(256) radix_hist_kernel(const K* keys, uint64_t n, int shift, uint32_t* hist, uint32_t nblocks) {
+__global__ void __launch_bounds__(256) radix_hist_kernel(const K* keys, uint64_t n, int shift, uint32_t* hist, uint32_t nblocks, uint32_t* digit_total) {
     constexpr int ND = 1 << DB;
     __shared__ uint32_t h[ND];
     for (int d = threadIdx.x; d < ND; d += 256) h[d] = 0u;
@@ -58,13 +74,61 @@ __global__ void __launch_bounds__(256) radix_hist_kernel(const K* keys, uint64_t
 #pragma unroll 4
     for (int k = 0; k < RS_TILE / 256; ++k) {
         const uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
-        if (i < n) atomicAdd(&h[(uint32_t)(keys[i] >> shift) & (ND - 1)], 1u);
+        const uint32_t d = i < n ? ((uint32_t)(keys[i] >> shift) & (ND - 1)) : 0xffffffffu;
+#if TA_RS_RUNS
+        const uint32_t len = run_length_at_head(d, (int)(threadIdx.x & 63));
+        if (len && i < n) atomicAdd(&h[d], len);
+#else
+        if (i < n) atomicAdd(&h[d], 1u);
+#endif
     }
     __syncthreads();
-    for (int d = threadIdx.x; d < ND; d += 256) hist[(uint64_t)d * nblocks + blockIdx.x] = h[d];
+    for (int d = threadIdx.x; d < ND; d += 256) {
+        hist[(uint64_t)d * nblocks + blockIdx.x] = h[d];
+        if (h[d]) atomicAdd(&digit_total[d], h[d]);          // (what the scan below starts each digit from: zeroed by the launcher)
+    }
+}
+
+// offs[d][b] = keys of smaller digits + keys of digit d in the workgroups before b: ONE kernel, a workgroup per digit (the generic
+// three-kernel scan over the digit-major table cost 22 us a pass on C2, launch-bound; the digit totals come from the histogram pass)
+template <int DB>
+__global__ void __launch_bounds__(256) radix_scan_kernel(const uint32_t* hist, uint32_t nblocks, const uint32_t* digit_total, uint64_t* offs) {
+    constexpr int ND = 1 << DB;
+    __shared__ uint32_t part[4], carry;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const uint32_t d = blockIdx.x;
+    uint32_t below = 0u;
+    for (uint32_t k = tid; k < d; k += 256) below += digit_total[k];
+    (void)ND;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) below += (uint32_t)__shfl_down((int)below, o, 64);
+    if (lane == 0) part[w] = below;
+    __syncthreads();
+    uint32_t run = part[0] + part[1] + part[2] + part[3];
+    __syncthreads();
+    const uint32_t* row = hist + (uint64_t)d * nblocks;
+    uint64_t* out = offs + (uint64_t)d * nblocks;
+    for (uint32_t b0 = 0; b0 < nblocks; b0 += 256) {
+        const uint32_t b = b0 + (uint32_t)tid;
+        const uint32_t v = b < nblocks ? row[b] : 0u;
+        uint32_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+        if (lane == 63) part[w] = incl;
+        __syncthreads();
+        uint32_t before = 0u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) before += k < w ? part[k] : 0u;
+        if (b < nblocks) out[b] = (uint64_t)(run + before + incl - v);
+        if (tid == 255) carry = before + incl;
+        __syncthreads();
+        run += carry;
+    }
 }
 
 struct __attribute__((packed, aligned(4))) WallInt3 { int32_t x, y, z; };
+// the values are linear voxel indices (memory order) when n2 != 0: the last pass makes the coordinates out of them
+struct WallLin { uint32_t n1, n2; int32_t inv[3]; };      // inv[i] = memory axis of array axis i
 
 // LAST = the pass of the most significant digit: the records themselves go to their places (pair unpacked from the key, the
 // coordinates fetched through the index) instead of keys and indices that a gather would have to read again.
@@ -75,7 +139,8 @@ struct __attribute__((packed, aligned(4))) WallInt3 { int32_t x, y, z; };
 template <typename K, int DB, bool LAST>
 __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* keys_in, const uint32_t* vals_in, uint64_t n, int shift,
                                                             const uint64_t* offs, uint32_t nblocks, K* keys_out, uint32_t* vals_out,
-                                                            const WallInt3* coords, uint2* pairs_out, WallInt3* coords_out, int bits) {
+                                                            const WallInt3* coords, uint2* pairs_out, WallInt3* coords_out, int bits,
+                                                            const WallLin lin) {
     constexpr int ND = 1 << DB;
     __shared__ uint32_t cursor[RS_WAVES][ND];           // first the digit counts of each wave, then its running cursors
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -92,7 +157,13 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* keys_in, co
         const uint64_t i = wbase + (uint64_t)c * 64 + lane;
         key[c] = i < n ? keys_in[i] : (K)0;
         val[c] = i < n ? vals_in[i] : 0u;
+#if TA_RS_RUNS
+        const uint32_t d = i < n ? ((uint32_t)(key[c] >> shift) & (ND - 1)) : 0xffffffffu;
+        const uint32_t len = run_length_at_head(d, lane);
+        if (len && i < n) atomicAdd(&cursor[w][d], len);
+#else
         if (i < n) atomicAdd(&cursor[w][(uint32_t)(key[c] >> shift) & (ND - 1)], 1u);
+#endif
     }
     __syncthreads();
     for (int d = tid; d < ND; d += 256) {   // a thread owns its digits: where the workgroup's keys of that digit start, then wave by wave
@@ -117,7 +188,17 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* keys_in, co
             if (LAST) {
                 const uint64_t k = (uint64_t)key[c];
                 pairs_out[pos] = make_uint2((uint32_t)(k >> bits), (uint32_t)(k & mask));
-                coords_out[pos] = coords[val[c]];
+                if (lin.n2) {
+                    const uint32_t row = val[c] / lin.n2;
+                    const int32_t mc = (int32_t)(val[c] - row * lin.n2), ma = (int32_t)(row / lin.n1), mb = (int32_t)(row - (uint32_t)ma * lin.n1);
+                    WallInt3 xyz;
+                    xyz.x = lin.inv[0] == 0 ? ma : (lin.inv[0] == 1 ? mb : mc);
+                    xyz.y = lin.inv[1] == 0 ? ma : (lin.inv[1] == 1 ? mb : mc);
+                    xyz.z = lin.inv[2] == 0 ? ma : (lin.inv[2] == 1 ? mb : mc);
+                    coords_out[pos] = xyz;
+                } else {
+                    coords_out[pos] = coords[val[c]];
+                }
             } else {
                 keys_out[pos] = key[c];
                 vals_out[pos] = val[c];
@@ -128,18 +209,19 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* keys_in, co
 
 static uint64_t rs_blocks(uint64_t n) { return (n + RS_TILE - 1) / RS_TILE; }
 
-// hist u32[digits][blocks] | offsets u64[digits][blocks] | scan scratch
+// hist u32[digits][blocks] | offsets u64[digits][blocks] | digit totals u32[passes][digits]
 uint64_t wall_sort_temp_bytes(uint64_t n) {
     const uint64_t cells = (uint64_t)(1 << RS_MAX_DIGIT_BITS) * rs_blocks(n);
-    return ((cells * 4 + 15) & ~15ull) + ((cells * 8 + 15) & ~15ull) + scan_u32_scratch_bytes(cells) + 64;
+    return ((cells * 4 + 15) & ~15ull) + ((cells * 8 + 15) & ~15ull) + 8 * (1u << RS_MAX_DIGIT_BITS) * sizeof(uint32_t) + 64;      // (+ digit totals of up to 8 passes)
 }
 
 template <typename K, int DB>
 static hipError_t wall_group_db(hipStream_t s, const uint32_t* pairs, const int32_t* coords, uint64_t n, K* keys0, K* keys1,
-                                uint32_t* index0, uint32_t* index1, void* temp, int bits, uint32_t* pairs_out, int32_t* coords_out) {
+                                uint32_t* index0, uint32_t* index1, void* temp, int bits, uint32_t* pairs_out, int32_t* coords_out,
+                                const WallLin lin) {
     unsigned blocks = (unsigned)((n + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(wall_sort_keys_kernel<K>, dim3(blocks), dim3(256), 0, s, (const uint2*)pairs, n, keys0, index0, bits);
+    if (pairs) hipLaunchKernelGGL(wall_sort_keys_kernel<K>, dim3(blocks), dim3(256), 0, s, (const uint2*)pairs, n, keys0, index0, bits);
     const uint32_t nb = (uint32_t)rs_blocks(n);
     const uint64_t cells = (uint64_t)(1 << DB) * nb;
     char* p = (char*)temp;
@@ -148,16 +230,19 @@ static hipError_t wall_group_db(hipStream_t s, const uint32_t* pairs, const int3
     K* kin = keys0; K* kout = keys1;
     uint32_t* vin = index0; uint32_t* vout = index1;
     const int passes = rs_passes(2 * bits);
+    uint32_t* totals = (uint32_t*)p;                       // [passes][digits]: keys of each digit, counted by the histogram passes
+    const hipError_t ez = hipMemsetAsync(totals, 0, (size_t)passes * (1 << DB) * sizeof(uint32_t), s);
+    if (ez != hipSuccess) return ez;
     for (int pass = 0; pass < passes; ++pass) {
         const int shift = pass * DB;
-        hipLaunchKernelGGL((radix_hist_kernel<K, DB>), dim3(nb), dim3(256), 0, s, kin, n, shift, hist, nb);
-        launch_scan_u32_exclusive(s, hist, cells, p, offs);
+        hipLaunchKernelGGL((radix_hist_kernel<K, DB>), dim3(nb), dim3(256), 0, s, kin, n, shift, hist, nb, totals + (size_t)pass * (1 << DB));
+        hipLaunchKernelGGL((radix_scan_kernel<DB>), dim3(1 << DB), dim3(256), 0, s, hist, nb, totals + (size_t)pass * (1 << DB), offs);
         if (pass + 1 < passes)
             hipLaunchKernelGGL((radix_scatter_kernel<K, DB, false>), dim3(nb), dim3(256), 0, s, kin, vin, n, shift, offs, nb, kout, vout,
-                               (const WallInt3*)nullptr, (uint2*)nullptr, (WallInt3*)nullptr, bits);
+                               (const WallInt3*)nullptr, (uint2*)nullptr, (WallInt3*)nullptr, bits, lin);
         else
             hipLaunchKernelGGL((radix_scatter_kernel<K, DB, true>), dim3(nb), dim3(256), 0, s, kin, vin, n, shift, offs, nb, kout, vout,
-                               (const WallInt3*)coords, (uint2*)pairs_out, (WallInt3*)coords_out, bits);
+                               (const WallInt3*)coords, (uint2*)pairs_out, (WallInt3*)coords_out, bits, lin);
         K* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
     }
@@ -166,12 +251,13 @@ static hipError_t wall_group_db(hipStream_t s, const uint32_t* pairs, const int3
 
 template <typename K>
 static hipError_t wall_group(hipStream_t s, const uint32_t* pairs, const int32_t* coords, uint64_t n, K* keys0, K* keys1,
-                             uint32_t* index0, uint32_t* index1, void* temp, int bits, uint32_t* pairs_out, int32_t* coords_out) {
+                             uint32_t* index0, uint32_t* index1, void* temp, int bits, uint32_t* pairs_out, int32_t* coords_out,
+                             const WallLin lin) {
     switch (rs_digit_bits(2 * bits)) {      // (2 .. 10: the widths a key of 2 .. 64 bits splits into; below 8: as 8)
-#define TA_RS_CASE(DB) case DB: return wall_group_db<K, DB>(s, pairs, coords, n, keys0, keys1, index0, index1, temp, bits, pairs_out, coords_out);
+#define TA_RS_CASE(DB) case DB: return wall_group_db<K, DB>(s, pairs, coords, n, keys0, keys1, index0, index1, temp, bits, pairs_out, coords_out, lin);
         TA_RS_CASE(10) TA_RS_CASE(9) TA_RS_CASE(8)
 #undef TA_RS_CASE
-        default: return wall_group_db<K, 8>(s, pairs, coords, n, keys0, keys1, index0, index1, temp, bits, pairs_out, coords_out);
+        default: return wall_group_db<K, 8>(s, pairs, coords, n, keys0, keys1, index0, index1, temp, bits, pairs_out, coords_out, lin);
     }
 }
 
@@ -185,10 +271,26 @@ hipError_t launch_wall_group_by_pair(hipStream_t s, const uint32_t* pairs, const
     if (n == 0) return hipSuccess;
     if (label_bits < 1) label_bits = 1;
     if (label_bits > 32) label_bits = 32;
+    const WallLin none = {0u, 0u, {0, 1, 2}};
     if (2 * label_bits <= 32)
         return wall_group<uint32_t>(s, pairs, coords, n, (uint32_t*)keys0, (uint32_t*)keys1, index0, index1, temp, label_bits,
-                                    pairs_out, coords_out);
-    return wall_group<uint64_t>(s, pairs, coords, n, keys0, keys1, index0, index1, temp, label_bits, pairs_out, coords_out);
+                                    pairs_out, coords_out, none);
+    return wall_group<uint64_t>(s, pairs, coords, n, keys0, keys1, index0, index1, temp, label_bits, pairs_out, coords_out, none);
+}
+
+hipError_t launch_wall_group_keyed(hipStream_t s, uint64_t n, uint64_t* keys0, uint64_t* keys1, uint32_t* index0, uint32_t* index1,
+                                   void* temp, int label_bits, const int64_t mdims[3], const int perm[3], uint32_t* pairs_out,
+                                   int32_t* coords_out) {
+    if (n == 0) return hipSuccess;
+    if (label_bits < 1) label_bits = 1;
+    if (label_bits > 32) label_bits = 32;
+    WallLin lin;
+    lin.n1 = (uint32_t)mdims[1]; lin.n2 = (uint32_t)mdims[2];
+    for (int k = 0; k < 3; ++k) lin.inv[perm[k]] = k;
+    if (2 * label_bits <= 32)
+        return wall_group<uint32_t>(s, nullptr, nullptr, n, (uint32_t*)keys0, (uint32_t*)keys1, index0, index1, temp, label_bits,
+                                    pairs_out, coords_out, lin);
+    return wall_group<uint64_t>(s, nullptr, nullptr, n, keys0, keys1, index0, index1, temp, label_bits, pairs_out, coords_out, lin);
 }
 
 }  // namespace ta

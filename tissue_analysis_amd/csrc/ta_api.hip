@@ -908,32 +908,42 @@ int wall_records_device(ta_ctx* c, bool by_pair, DevBuf& buf, uint32_t** pairs_d
     (void)wall_bufs(c->wall_counts.p, plan, wb);
     wb.region = c->wall_region;
     wb.stage = c->wall_region ? c->wall_stage.p : nullptr;
-    // one allocation: records in memory order | (grouped fetch) the same again grouped, sort keys / indices x 2, sort temp
+    // one allocation: records in memory order | (grouped fetch) the same again grouped, sort keys / indices x 2, sort temp.
+    // A volume of fewer than 2^32 voxels is grouped from KEYS: the fetch writes sort keys and linear voxel indices straight into
+    // the sort's buffers (no records in memory order, no key pass, no gather of coordinates behind the last pass)
+    const uint64_t nvox = (uint64_t)c->mdims[0] * (uint64_t)c->mdims[1] * (uint64_t)c->mdims[2];
+    // (tests and same-call comparisons: TA_WALL_KEYED=0 sorts the records of the plain fetch, as volumes of 2^32 voxels and more do)
+    const char* env_keyed = getenv("TA_WALL_KEYED");
+    const bool keyed = by_pair && nvox < (1ull << 32) && !(env_keyed && env_keyed[0] == '0');
     const uint64_t temp_bytes = by_pair ? ta::wall_sort_temp_bytes(n) : 0;
     const uint64_t rec = n * 8, co = (n * 12 + 15) & ~15ull, ix = (n * 4 + 15) & ~15ull;
-    if ((rc = buf.reserve(by_pair ? 2 * rec + 2 * co + 2 * rec + 2 * ix + temp_bytes + 64 : rec + co)) != TA_OK) return rc;
+    if ((rc = buf.reserve(by_pair ? (keyed ? 0 : rec + co) + rec + co + 2 * rec + 2 * ix + temp_bytes + 64 : rec + co)) != TA_OK) return rc;
     char* p = (char*)buf.p;
-    uint32_t* dpa = (uint32_t*)p; p += rec;
-    int32_t* dco = (int32_t*)p; p += co;
+    int label_bits = 1;                                             // bits a label of this volume takes
+    while (label_bits < 32 && (c->wall_label_or >> label_bits) != 0u) ++label_bits;
+    uint32_t* dpa = nullptr; int32_t* dco = nullptr;
+    if (!keyed) { dpa = (uint32_t*)p; p += rec; dco = (int32_t*)p; p += co; }
     uint32_t* gpa = dpa; int32_t* gco = dco;
-    hipError_t e = e0 ? hipEventRecord(e0, c->stream) : hipSuccess;
-    if (e == hipSuccess) {
-        // records leave the kernels as (lo, hi) / coordinates in ARRAY-axis order
-        ta::launch_wall_fetch(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], wb, c->wall_wide,
-                              c->wall_not_staged, dpa, dco, c->perm);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess && by_pair) {
+    uint64_t *k0 = nullptr, *k1 = nullptr; uint32_t *i0 = nullptr, *i1 = nullptr;
+    if (by_pair) {
         gpa = (uint32_t*)p; p += rec;
         gco = (int32_t*)p; p += co;
-        uint64_t* k0 = (uint64_t*)p; p += rec;
-        uint64_t* k1 = (uint64_t*)p; p += rec;
-        uint32_t* i0 = (uint32_t*)p; p += ix;
-        uint32_t* i1 = (uint32_t*)p; p += ix;
-        int label_bits = 1;                                         // bits a label of this volume takes
-        while (label_bits < 32 && (c->wall_label_or >> label_bits) != 0u) ++label_bits;
-        e = ta::launch_wall_group_by_pair(c->stream, dpa, dco, n, k0, k1, i0, i1, p, temp_bytes, label_bits, gpa, gco);
+        k0 = (uint64_t*)p; p += rec;
+        k1 = (uint64_t*)p; p += rec;
+        i0 = (uint32_t*)p; p += ix;
+        i1 = (uint32_t*)p; p += ix;
     }
+    hipError_t e = e0 ? hipEventRecord(e0, c->stream) : hipSuccess;
+    if (e == hipSuccess) {
+        // records leave the kernels as (lo, hi) / coordinates in ARRAY-axis order -- or as keys / linear indices for the sort
+        ta::launch_wall_fetch(c->stream, c->vol, c->itemsize, c->mdims[0], c->mdims[1], c->mdims[2], wb, c->wall_wide,
+                              c->wall_not_staged, keyed ? (uint32_t*)k0 : dpa, keyed ? (int32_t*)i0 : dco, c->perm, keyed ? label_bits : 0);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess && keyed)
+        e = ta::launch_wall_group_keyed(c->stream, n, k0, k1, i0, i1, p, label_bits, c->mdims, c->perm, gpa, gco);
+    else if (e == hipSuccess && by_pair)
+        e = ta::launch_wall_group_by_pair(c->stream, dpa, dco, n, k0, k1, i0, i1, p, temp_bytes, label_bits, gpa, gco);
     if (e == hipSuccess && e1) e = hipEventRecord(e1, c->stream);
     if (e != hipSuccess) return fail(TA_EHIP, "wall voxels: %s", hipGetErrorString(e));
     *pairs_dev = gpa; *coords_dev = gco;

@@ -60,13 +60,19 @@ uint32_t wall_stage_regions();
 void launch_wall_count(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2, const WallBuffers& b,
                        bool wide);
 void launch_wall_fetch(hipStream_t s, const void* vol, int itemsize, int64_t n0, int64_t n1, int64_t n2, const WallBuffers& b,
-                       bool wide, uint32_t not_staged, uint32_t* out_pairs, int32_t* out_coords, const int perm[3]);
+                       bool wide, uint32_t not_staged, uint32_t* out_pairs, int32_t* out_coords, const int perm[3], int key_bits = 0);
 
 // kernels_wallsort.hip -- the records grouped by pair (stable radix sort by lo << 32 | hi, then a gather)
 uint64_t wall_sort_temp_bytes(uint64_t n);
 hipError_t launch_wall_group_by_pair(hipStream_t s, const uint32_t* pairs, const int32_t* coords, uint64_t n, uint64_t* keys0,
                                      uint64_t* keys1, uint32_t* index0, uint32_t* index1, void* temp, uint64_t temp_bytes,
                                      int label_bits, uint32_t* pairs_out, int32_t* coords_out);
+// ... from sort keys and linear voxel indices the fetch has written itself (launch_wall_fetch with key_bits = label_bits, into
+// keys0 / index0): no key pass, and the last pass makes the coordinates out of the index instead of gathering them.
+// mdims: the volume in memory order; perm[k] = array axis of memory axis k
+hipError_t launch_wall_group_keyed(hipStream_t s, uint64_t n, uint64_t* keys0, uint64_t* keys1, uint32_t* index0, uint32_t* index1,
+                                   void* temp, int label_bits, const int64_t mdims[3], const int perm[3], uint32_t* pairs_out,
+                                   int32_t* coords_out);
 
 // kernels_walls.hip (continued): exclusive scan of uint32 counts into uint64 offsets (three small kernels)
 uint64_t scan_u32_scratch_bytes(uint64_t n);

@@ -92,7 +92,8 @@ struct SumPack {
     }
 };
 // the tallest tile each kind of sweep kernel packs its sums for (launches clamp the tile height to it; results never depend on it)
-constexpr int tile_planes_cap(bool adjacency, int itemsize, int vpl) { (void)itemsize; return adjacency ? (vpl == 4 ? 48 : TA_PLANES_CAP_ADJ8) : 16; }
+// (moments only: uint16 tiles are 8 rows x 512 columns like the wide adjacency tiles; uint32 tiles 16 rows x 256, whose four words end at 16 planes)
+constexpr int tile_planes_cap(bool adjacency, int itemsize, int vpl) { return adjacency ? (vpl == 4 ? 48 : TA_PLANES_CAP_ADJ8) : (itemsize == 2 ? 32 : 16); }
 
 // shift tile-local sums to global coordinates (origin A0,B0,C0): exact u64
 __device__ __forceinline__ void local_to_global(const LocalSums& L, uint64_t A0, uint64_t B0, uint64_t C0,
