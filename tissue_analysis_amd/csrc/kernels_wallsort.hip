@@ -4,8 +4,11 @@
 // label of this volume takes, found by the count pass, so the sort runs over 2 x bits instead of 64 -- with the record index
 // as value; stable, so each pair's voxels stay in memory order.  The key splits into as few digits of at most 10 bits as it
 // takes, all of one width (28 or 30 bits: three passes of 10; 32: four of 8).  Three kernels a pass:
-//   histogram  a workgroup counts the digits of its tile of 4096 keys in LDS and writes hist[digit][workgroup];
-//   scan       an exclusive scan over that table (digit-major) = where each workgroup's keys of each digit start;
+//   histogram  a workgroup counts the digits of its tile of 4096 keys in LDS and writes its ROW hist[workgroup][digit] (one coalesced
+//              store; a digit-major table cost every workgroup 512 scattered 4-byte writes, and the scatter as many scattered reads)
+//              and adds the row to the totals of its SEGMENT of 64 workgroups;
+//   offsets    where each workgroup's keys of each digit start: a thread per (segment, digit) adds the keys of smaller digits and of
+//              the digit in earlier segments (totals the histogram pass has added up), then walks the 64 rows of its segment;
 //   scatter    a wave owns 1024 consecutive keys of the tile and walks them 64 at a time, IN ORDER: a lane's rank among the
 //              lanes of its chunk that hold the same digit comes from one ballot per digit bit, its position from the wave's
 //              running cursor of that digit in LDS -- no key ever overtakes an equal one.  The LAST pass writes the records
@@ -17,6 +20,8 @@ namespace ta {
 
 constexpr int RS_WAVES = 4, RS_PER_WAVE = 1024, RS_TILE = RS_WAVES * RS_PER_WAVE;      // keys per workgroup
 constexpr int RS_MAX_DIGIT_BITS = 10;
+constexpr uint32_t RS_COPIES = 8;                    // copies of the digit totals the histogram workgroups add to (blockIdx mod copies)
+constexpr uint32_t RS_SEG = 64;                       // workgroups (rows of the digit table) a segment of the offset scan
 #ifndef TA_RS_RUNS
 #define TA_RS_RUNS 1       // digits are counted a RUN of equal neighbours at a time (0: a key at a time, round 4)
 #endif
@@ -65,7 +70,7 @@ __device__ __forceinline__ uint32_t run_length_at_head(const uint32_t d, const i
 //  built and is SLOWER -- C2 1.98 against 1.44 ms for the grouped fetch: three rounds of eight ballots a chunk and a
 //  read-modify-write the wave has to wait for cost more than the serialised atomics nobody waits for.)
 template <typename K, int DB>
-__global__ void __launch_bounds__(256) radix_hist_kernel(const K* keys, uint64_t n, int shift, uint32_t* hist, uint32_t nblocks, uint32_t* digit_total) {
+__global__ void __launch_bounds__(256) radix_hist_kernel(const K* keys, uint64_t n, int shift, uint32_t* hist, uint32_t* seg_total, uint32_t* digit_total) {
     constexpr int ND = 1 << DB;
     __shared__ uint32_t h[ND];
     for (int d = threadIdx.x; d < ND; d += 256) h[d] = 0u;
@@ -83,46 +88,52 @@ __global__ void __launch_bounds__(256) radix_hist_kernel(const K* keys, uint64_t
 #endif
     }
     __syncthreads();
+    // the row also goes to the totals of its segment and to one of RS_COPIES copies of the digit totals of the whole array (one copy:
+    // 3655 atomics on each of 512 words, +9 us a pass on C2; the workgroup that finishes a segment last adding the segment's totals
+    // needs a device-scope fence in every workgroup -- an L2 write-back each on this chip: 0.33 ms a pass)
+    const uint32_t seg = blockIdx.x / RS_SEG, copy = blockIdx.x % RS_COPIES;
     for (int d = threadIdx.x; d < ND; d += 256) {
-        hist[(uint64_t)d * nblocks + blockIdx.x] = h[d];
-        if (h[d]) atomicAdd(&digit_total[d], h[d]);          // (what the scan below starts each digit from: zeroed by the launcher)
+        hist[(uint64_t)blockIdx.x * ND + d] = h[d];
+        if (h[d]) { atomicAdd(&seg_total[(uint64_t)seg * ND + d], h[d]); atomicAdd(&digit_total[copy * ND + d], h[d]); }      // (zeroed by the launcher)
     }
 }
 
-// offs[d][b] = keys of smaller digits + keys of digit d in the workgroups before b: ONE kernel, a workgroup per digit (the generic
-// three-kernel scan over the digit-major table cost 22 us a pass on C2, launch-bound; the digit totals come from the histogram pass)
+// offs[b][d] for the rows b of one segment: a thread per digit.  Where the digit starts in its segment = keys of smaller digits
+// (an exclusive scan of the digit totals, redone by every workgroup: 2^DB words) + keys of the digit in the segments before
+// (their totals, one coalesced row each), then the thread walks the rows of its segment.
+// (a separate one-workgroup kernel for the segment bases took 20 us a pass on C2: one workgroup cannot keep enough loads in flight)
 template <int DB>
-__global__ void __launch_bounds__(256) radix_scan_kernel(const uint32_t* hist, uint32_t nblocks, const uint32_t* digit_total, uint64_t* offs) {
+__global__ void __launch_bounds__(256) radix_offsets_kernel(const uint32_t* hist, uint32_t nblocks, const uint32_t* seg_total,
+                                                            const uint32_t* digit_total, uint32_t* offs) {
     constexpr int ND = 1 << DB;
-    __shared__ uint32_t part[4], carry;
+    __shared__ uint32_t part[4], low[4];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const uint32_t d = blockIdx.x;
-    uint32_t below = 0u;
-    for (uint32_t k = tid; k < d; k += 256) below += digit_total[k];
-    (void)ND;
+    const uint32_t d = blockIdx.y * 256u + (uint32_t)tid, seg = blockIdx.x;
+    uint32_t lower = 0u;                                           // keys of the digits below this workgroup's 256
+    for (uint32_t c = 0; c < RS_COPIES; ++c)
+        for (uint32_t k = (uint32_t)tid; k < blockIdx.y * 256u; k += 256u) lower += digit_total[c * ND + k];
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) below += (uint32_t)__shfl_down((int)below, o, 64);
-    if (lane == 0) part[w] = below;
+    for (int o = 32; o > 0; o >>= 1) lower += (uint32_t)__shfl_down((int)lower, o, 64);
+    uint32_t mine = 0u;
+#pragma unroll
+    for (uint32_t c = 0; c < RS_COPIES; ++c) mine += d < (uint32_t)ND ? digit_total[c * ND + d] : 0u;
+    uint32_t incl = mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
+    if (lane == 0) low[w] = lower;
+    if (lane == 63) part[w] = incl;
     __syncthreads();
-    uint32_t run = part[0] + part[1] + part[2] + part[3];
-    __syncthreads();
-    const uint32_t* row = hist + (uint64_t)d * nblocks;
-    uint64_t* out = offs + (uint64_t)d * nblocks;
-    for (uint32_t b0 = 0; b0 < nblocks; b0 += 256) {
-        const uint32_t b = b0 + (uint32_t)tid;
-        const uint32_t v = b < nblocks ? row[b] : 0u;
-        uint32_t incl = v;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)incl, o, 64); if (lane >= o) incl += t; }
-        if (lane == 63) part[w] = incl;
-        __syncthreads();
-        uint32_t before = 0u;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) before += k < w ? part[k] : 0u;
-        if (b < nblocks) out[b] = (uint64_t)(run + before + incl - v);
-        if (tid == 255) carry = before + incl;
-        __syncthreads();
-        run += carry;
+    uint32_t run = low[0] + low[1] + low[2] + low[3] + incl - mine;
+    for (int k = 0; k < w; ++k) run += part[k];
+    if (d >= (uint32_t)ND) return;
+#pragma unroll 8
+    for (uint32_t s = 0; s < seg; ++s) run += seg_total[(uint64_t)s * ND + d];
+    const uint32_t b0 = seg * RS_SEG, b1 = b0 + RS_SEG < nblocks ? b0 + RS_SEG : nblocks;
+#pragma unroll 8
+    for (uint32_t b = b0; b < b1; ++b) {
+        const uint32_t v = hist[(uint64_t)b * ND + d];
+        offs[(uint64_t)b * ND + d] = run;
+        run += v;
     }
 }
 
@@ -138,7 +149,7 @@ struct WallLin { uint32_t n1, n2; int32_t inv[3]; };      // inv[i] = memory axi
 //  9.5 ms; tiles of 8192 keys: no change.)
 template <typename K, int DB, bool LAST>
 __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* keys_in, const uint32_t* vals_in, uint64_t n, int shift,
-                                                            const uint64_t* offs, uint32_t nblocks, K* keys_out, uint32_t* vals_out,
+                                                            const uint32_t* offs, K* keys_out, uint32_t* vals_out,
                                                             const WallInt3* coords, uint2* pairs_out, WallInt3* coords_out, int bits,
                                                             const WallLin lin) {
     constexpr int ND = 1 << DB;
@@ -167,7 +178,7 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* keys_in, co
     }
     __syncthreads();
     for (int d = tid; d < ND; d += 256) {   // a thread owns its digits: where the workgroup's keys of that digit start, then wave by wave
-        uint32_t at = (uint32_t)offs[(uint64_t)d * nblocks + blockIdx.x];
+        uint32_t at = offs[(uint64_t)blockIdx.x * ND + d];
 #pragma unroll
         for (int k = 0; k < RS_WAVES; ++k) { const uint32_t cnt = cursor[k][d]; cursor[k][d] = at; at += cnt; }
     }
@@ -207,12 +218,13 @@ __global__ void __launch_bounds__(256) radix_scatter_kernel(const K* keys_in, co
     }
 }
 
-static uint64_t rs_blocks(uint64_t n) { return (n + RS_TILE - 1) / RS_TILE; }
 
-// hist u32[digits][blocks] | offsets u64[digits][blocks] | digit totals u32[passes][digits]
+static uint64_t rs_blocks(uint64_t n) { return (n + RS_TILE - 1) / RS_TILE; }
+static uint64_t rs_segments(uint64_t n) { return (rs_blocks(n) + RS_SEG - 1) / RS_SEG; }
+// hist u32[blocks][digits] | offsets u32[blocks][digits] | per pass (<= 8): segment totals [segments][digits], digit totals [copies][digits]
 uint64_t wall_sort_temp_bytes(uint64_t n) {
-    const uint64_t cells = (uint64_t)(1 << RS_MAX_DIGIT_BITS) * rs_blocks(n);
-    return ((cells * 4 + 15) & ~15ull) + ((cells * 8 + 15) & ~15ull) + 8 * (1u << RS_MAX_DIGIT_BITS) * sizeof(uint32_t) + 64;      // (+ digit totals of up to 8 passes)
+    const uint64_t nd = 1u << RS_MAX_DIGIT_BITS, cells = nd * rs_blocks(n);
+    return 2 * ((cells * 4 + 15) & ~15ull) + 8 * (rs_segments(n) + RS_COPIES) * nd * sizeof(uint32_t) + 64;
 }
 
 template <typename K, int DB>
@@ -226,22 +238,27 @@ static hipError_t wall_group_db(hipStream_t s, const uint32_t* pairs, const int3
     const uint64_t cells = (uint64_t)(1 << DB) * nb;
     char* p = (char*)temp;
     uint32_t* hist = (uint32_t*)p; p += (cells * 4 + 15) & ~15ull;
-    uint64_t* offs = (uint64_t*)p; p += (cells * 8 + 15) & ~15ull;
+    uint32_t* offs = (uint32_t*)p; p += (cells * 4 + 15) & ~15ull;
+    const uint32_t nseg = (uint32_t)rs_segments(n);
+    const size_t seg_words = (size_t)nseg * (1 << DB);
     K* kin = keys0; K* kout = keys1;
     uint32_t* vin = index0; uint32_t* vout = index1;
     const int passes = rs_passes(2 * bits);
-    uint32_t* totals = (uint32_t*)p;                       // [passes][digits]: keys of each digit, counted by the histogram passes
-    const hipError_t ez = hipMemsetAsync(totals, 0, (size_t)passes * (1 << DB) * sizeof(uint32_t), s);
+    // per pass: segment totals [segments][digits] | digit totals [copies][digits]
+    uint32_t* totals = (uint32_t*)p;
+    const size_t pass_words = seg_words + (size_t)RS_COPIES * (1 << DB);
+    const hipError_t ez = hipMemsetAsync(totals, 0, (size_t)passes * pass_words * sizeof(uint32_t), s);
     if (ez != hipSuccess) return ez;
     for (int pass = 0; pass < passes; ++pass) {
         const int shift = pass * DB;
-        hipLaunchKernelGGL((radix_hist_kernel<K, DB>), dim3(nb), dim3(256), 0, s, kin, n, shift, hist, nb, totals + (size_t)pass * (1 << DB));
-        hipLaunchKernelGGL((radix_scan_kernel<DB>), dim3(1 << DB), dim3(256), 0, s, hist, nb, totals + (size_t)pass * (1 << DB), offs);
+        uint32_t* seg_total = totals + (size_t)pass * pass_words;
+        hipLaunchKernelGGL((radix_hist_kernel<K, DB>), dim3(nb), dim3(256), 0, s, kin, n, shift, hist, seg_total, seg_total + seg_words);
+        hipLaunchKernelGGL((radix_offsets_kernel<DB>), dim3(nseg, ((1 << DB) + 255) / 256), dim3(256), 0, s, hist, nb, seg_total, seg_total + seg_words, offs);
         if (pass + 1 < passes)
-            hipLaunchKernelGGL((radix_scatter_kernel<K, DB, false>), dim3(nb), dim3(256), 0, s, kin, vin, n, shift, offs, nb, kout, vout,
+            hipLaunchKernelGGL((radix_scatter_kernel<K, DB, false>), dim3(nb), dim3(256), 0, s, kin, vin, n, shift, offs, kout, vout,
                                (const WallInt3*)nullptr, (uint2*)nullptr, (WallInt3*)nullptr, bits, lin);
         else
-            hipLaunchKernelGGL((radix_scatter_kernel<K, DB, true>), dim3(nb), dim3(256), 0, s, kin, vin, n, shift, offs, nb, kout, vout,
+            hipLaunchKernelGGL((radix_scatter_kernel<K, DB, true>), dim3(nb), dim3(256), 0, s, kin, vin, n, shift, offs, kout, vout,
                                (const WallInt3*)coords, (uint2*)pairs_out, (WallInt3*)coords_out, bits, lin);
         K* tk = kin; kin = kout; kout = tk;
         uint32_t* tv = vin; vin = vout; vout = tv;
