@@ -29,10 +29,11 @@ done
 #   noflush = the tile tables are not flushed; hot1 = ... and the top-of-plane drains add nothing to the tables; hot2 = ... and run
 #   no probe rounds; hot4 = ... and read neither keys nor records; noslow = ... and the in-plane drains / the end of the tile consume
 #   nothing; abl1 = nothing is consumed anywhere (records produced and stored); abl3 = not even placed (compares + counts + scan);
-#   nf01 (not cumulative) = no axis-0 / axis-1 face records; nomask = the pre-round-5 record stores (trash slot, five VALU a position)
+#   nf01 (not cumulative) = no axis-0 / axis-1 face records; nomask = the pre-round-5 record stores (trash slot, five VALU a position);
+#   nohalo1 = a workgroup's first wave reads no row above (12.5 % fewer bytes fetched); notr = the flush adds a label's sums lane = label
 OUT=gpurun_out/${TAG}_ablations.txt
 : > $OUT
-for a in base noflush hot1 hot2 hot4 noslow abl1 abl3 nf01 nomask base; do
+for a in base noflush hot1 hot2 hot4 noslow abl1 abl3 nf01 nomask nohalo1 notr base; do
   if [ "$a" = base ] || [ -f scratch/lib$a.so ]; then
     echo "ablation $a" >> $OUT
     if [ "$a" = base ]; then unset TISSUE_SCAN_LIB; else export TISSUE_SCAN_LIB=$R/scratch/lib$a.so; fi
@@ -65,6 +66,13 @@ python3 scripts/probe_walls.py C2 2>&1 | tail -2 >> $OUT
 # PMC passes of the wide kernel and its abl1 / nf01 builds on C4 and on the tissue-filled C4 (instruction counts, LDS, waits)
 bash scripts/run_pmc_ablations.sh ${TAG} --shape 1 -- base abl1 nf01 > /dev/null 2>&1
 bash scripts/run_pmc_ablations.sh ${TAG}f --shape 1 --no-ellipsoid -- base abl1 > /dev/null 2>&1
+# the wall-voxel passes on C2: kernel stats of two plain + two grouped fetches (scripts/prof_walls.sh), and the record sort of round 4
+# (TA_WALL_KEYED=0: the plain fetch's records sorted, a key pass before and a coordinate gather behind) in the same call
+timeout -k 10 300 bash scripts/prof_walls.sh ${TAG} > gpurun_out/${TAG}_walls_summary.txt 2>&1
+python3 scripts/probe_walls.py C2 2>&1 | grep "grouped\|records" >> gpurun_out/${TAG}_walls_summary.txt
+TA_WALL_KEYED=0 python3 scripts/probe_walls.py C2 2>&1 | grep "grouped" | sed 's/^/TA_WALL_KEYED=0 /' >> gpurun_out/${TAG}_walls_summary.txt
+python3 scripts/probe_walls.py C3 2>&1 | grep "grouped\|records" >> gpurun_out/${TAG}_walls_summary.txt
+cd $R
 if [ -f scratch/pipes_bench ]; then ./scratch/pipes_bench > gpurun_out/${TAG}_pipes.txt 2>&1; fi
 python3 scripts/update_pmc_traffic.py C4 gpurun_out/prof_${TAG}_pmc.txt --note "default bench" > gpurun_out/${TAG}_traffic.txt 2>&1
 cp profiles/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
