@@ -163,7 +163,9 @@ def test_table_spills_keep_every_mask_exact(gpu_ctx):
 def test_repeated_sweeps_of_a_spilling_volume_adapt_the_tile_height(gpu_ctx):
     """The automatic tile height is halved (for the following sweeps of the same resident volume) when the workgroup
     tables overflow: same results, fewer spills."""
-    vol = random_blocks((96, 64, 512), 40000, 18, np.uint32, block=(5, 4, 9))
+    # (blocks small enough that a tile of the default height -- 40 planes of the narrow shape since round 5 -- overflows its tables:
+    #  180 k spills in the first sweep, 5 k from the second on; scripts/r05_spill_probe.py)
+    vol = random_blocks((96, 64, 512), 60000, 18, np.uint32, block=(4, 3, 9))
     want = onepass_c.extract(vol)
     gpu_ctx.set_option(_capi.OPT_TILE_PLANES, 0)
     gpu_ctx.set_option(_capi.OPT_IMPL, 0)

@@ -1667,7 +1667,10 @@ uint64_t sweep_grid_size(const SweepArgs& a, int itemsize, bool adjacency) {
 // they walk twice the planes for the same voxels per workgroup (40 and 48 measure the same, 24 is 3 % slower, 64 1 %).
 // (The wide uint32 tiles -- 8 rows x 512 columns -- hold twice the voxels a plane: 32 planes measure best on C4 and C5, and at
 //  48 the tissue-filled volume overflows the workgroup tables.)
-int sweep_default_tile_planes(bool adjacency, int itemsize, int shape) { return adjacency ? (itemsize == 4 ? (shape ? 32 : 48) : 32) : 16; }
+// (Round 5, after the flush got cheaper: the narrow tiles measure best at 40 planes -- tissue-filled 1.221 against 1.236 ms at 48 and 1.241 at 32, C4
+//  0.970 against 0.978; the wide tiles at 24 .. 32 on C4 (within the noise), 32 on C5, 24 where every tile is tissue: profiles/r05_tile_planes.txt.)
+// (uint16 volumes: 1024^3 0.681 / 0.684 ms at 28 planes against 0.686 / 0.688 at 32, 0.683 / 0.687 at 24; C2 is cut shorter by the launch anyway)
+int sweep_default_tile_planes(bool adjacency, int itemsize, int shape) { return adjacency ? (itemsize == 4 ? (shape ? 32 : 40) : 28) : 16; }
 int sweep_tile_planes_limit() { return MAX_TILE_PLANES; }
 // the tile height a kernel's packed sums are sized for (SumPack; results do not depend on the tile height)
 int sweep_max_tile_planes(bool adjacency, int itemsize, int shape) {

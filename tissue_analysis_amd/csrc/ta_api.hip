@@ -171,6 +171,7 @@ void drop_census(ta_ctx* c) {          // (whenever the voxels change)
     c->rerank_check = false;
     c->vol_max = -1;
     c->shape_pick = -1;
+    c->shape_density = -1.0;
     c->tune_launched = 0;
     for (bool& d : c->tune_done) d = false;
     if (c->compact) { c->compact = false; c->extracted = c->checked = false; }
@@ -238,6 +239,7 @@ double sampled_event_density(ta_ctx* c) {
 // below it the wide ones (fewer plane steps where most steps are background).  Same box, same call, round 5: C4 (0.023 changes a
 // voxel) wide 0.98 vs narrow 1.01 ms; the same cells without the ellipsoid (0.054) 1.38 vs 1.28 ms.
 constexpr double SHAPE_DENSITY_NARROW = 0.032;
+constexpr double WIDE_SHORTER_TILES_DENSITY = 0.02;       // (see run_extract: the default tile height of the wide tiles)
 
 // The sweep shape of this launch; *tune = the measuring slot (0 .. 3) whose events bracket it, or -1.
 int sweep_shape(ta_ctx* c, bool adjacency, int* tune) {
@@ -291,6 +293,10 @@ int run_extract(ta_ctx* c) {
     c->last_shape = a.shape;
     a.tile_planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY, c->itemsize, a.shape);
     if (c->tile_planes <= 0) {
+        // the wide tiles of a volume whose sampled planes change label often hold more labels and pairs a plane: a little shorter
+        // (C4, 0.023 changes a voxel: 28 planes 0.948 against 0.954 ms at 32; C5, 0.014: 32 planes 6.546 against 6.562 at 28 --
+        // profiles/r05_tile_planes.txt; without a measured density -- a forced shape -- the default stays)
+        if (a.shape == 1 && c->shape_density >= WIDE_SHORTER_TILES_DENSITY && a.tile_planes > 28) a.tile_planes = 28;
         // automatic: small volumes get shorter tiles until the launch has >= 2048 workgroups (8 per CU)
         while (a.tile_planes > 8 && ta::sweep_grid_size(a, c->itemsize, c->feature_mask & TA_F_ADJACENCY) < 2048) a.tile_planes /= 2;
         // volumes whose cells are so small that a tile holds more labels than the workgroup tables (the contributions
@@ -555,6 +561,7 @@ TA_API int ta_ctx_set_option(ta_ctx* c, int key, int64_t value) {
             c->opt_shape = (int)value;
             c->auto_tile_shift = 0;
             c->shape_pick = -1;                    // (decided again, by the new rule, at the next sweep)
+            c->shape_density = -1.0;
             c->tune_launched = 0;
             for (bool& d : c->tune_done) d = false;
             return TA_OK;
@@ -593,7 +600,13 @@ TA_API int ta_ctx_get_option(ta_ctx* c, int key, int64_t* value) {
         case TA_OPT_SWEEP_SHAPE_USED: *value = c->last_shape; return TA_OK;
         case TA_OPT_TIMING: *value = c->timing; return TA_OK;
         case TA_OPT_TIMING_RING: *value = (int64_t)(c->ring.size() / 2); return TA_OK;
-        case TA_OPT_TILE_PLANES: *value = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY, c->itemsize, c->opt_shape >= 0 ? c->opt_shape : (c->shape_pick >= 0 ? c->shape_pick : 1)); return TA_OK;
+        case TA_OPT_TILE_PLANES: {
+            const int shape = c->opt_shape >= 0 ? c->opt_shape : (c->shape_pick >= 0 ? c->shape_pick : 1);
+            int planes = c->tile_planes > 0 ? c->tile_planes : ta::sweep_default_tile_planes(c->feature_mask & TA_F_ADJACENCY, c->itemsize, shape);
+            if (c->tile_planes <= 0 && c->itemsize == 4 && (c->feature_mask & TA_F_ADJACENCY) && shape == 1 &&
+                c->shape_density >= WIDE_SHORTER_TILES_DENSITY && planes > 28) planes = 28;      // (the rule of run_extract)
+            *value = planes; return TA_OK;
+        }
         case TA_OPT_PAIR_SLOTS: *value = c->pkeys.p ? c->pair_log2 : c->opt_pair_log2; return TA_OK;
         default: return fail(TA_EINVAL, "unknown option key %d", key);
     }
