@@ -373,7 +373,8 @@ def main():
                          "traffic_note": traffic_note, "kernel": kernel_name,
                          "kernel_ms": round(sweep, 4), "kernel_launches_timed": len(sweep_ms),
                          "adjacency_collect_ms": round(float(np.mean(adj_ms)), 4),
-                         "algorithmic_bytes_per_launch": int(bytes_read)},
+                         "algorithmic_bytes_per_launch": int(bytes_read),
+                         "tile_planes": int(last_ctx().get_option(_capi.OPT_TILE_PLANES))},
         }
         if gather_ms is not None:
             out["secondary"] = {"global_adjacency_gather_ms": {"value": round(gather_ms, 3), "pairs": global_pairs,
